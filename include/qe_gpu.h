@@ -1,0 +1,251 @@
+/*
+ * qe_gpu.h — C ABI of the MI355X (gfx950) execution backend for the
+ * query-engine physical plan (Scan -> Selection -> Projection -> Aggregate).
+ *
+ * Every entry point is `extern "C"`, takes plain pointers / sizes / opaque
+ * handles and returns a `qe_status` (0 = OK).  Nothing aborts or throws across
+ * this boundary: where the reference panics (`unwrap()`), the matching call
+ * returns an error code and `qe_last_error_message()` holds the text.
+ *
+ * The reference (Rust) has no FFI layer; the interface replaced here is the
+ * set of Rust traits / constructors cited on each declaration
+ * (paths relative to /root/reference/query-engine/src/).
+ *
+ * Threading: handles are not thread-safe (the reference has no Send/Sync
+ * bounds: physical_plan/mod.rs:58).  One context = one HIP device + one
+ * stream; use one context per host thread / per GPU.
+ *
+ * Data layout: Arrow columnar.  Primitive = values buffer + optional validity
+ * bitmap (LSB first, 1 = valid); Boolean = bit-packed values + validity;
+ * Utf8 = int32 offsets[n+1] + bytes + validity (columnar_value.rs:1-5).
+ */
+#ifndef QE_GPU_H
+#define QE_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t qe_status;
+
+/* Status codes.  10..24 map 1:1 onto the variants of the reference's
+ * `enum Error` (error.rs:3-35), in declaration order. */
+enum {
+  QE_OK = 0,
+  QE_END = 1, /* iterator exhausted (the reference's `None` from next()) */
+  QE_ERR_EXCEEDING_BOUNDS = 10,               /* error.rs:5  */
+  QE_ERR_NO_FIELD_IN_LOGICAL_PLAN = 11,       /* error.rs:7  */
+  QE_ERR_DIFFERENT_SIZES = 12,                /* error.rs:9  */
+  QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED = 13, /* error.rs:11 */
+  QE_ERR_PHYSICAL_PLAN_NOT_SUPPORTED = 14,    /* error.rs:13 */
+  QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED = 15,    /* error.rs:15 */
+  QE_ERR_PRIMITIVE_TYPE_NOT_SUPPORTED = 16,   /* error.rs:17 */
+  QE_ERR_MISSING_CHILDREN = 17,               /* error.rs:19 */
+  QE_ERR_MISSING_INPUT_PHYSICAL_PLAN = 18,    /* error.rs:21 */
+  QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE = 19,    /* error.rs:23 */
+  QE_ERR_DOWNCAST = 20,                       /* error.rs:25 */
+  QE_ERR_SCALAR_TO_ARRAY = 21,                /* error.rs:27 */
+  QE_ERR_NO_BOOLEAN_ARRAY_FOR_FILTER = 22,    /* error.rs:29 */
+  QE_ERR_IO = 23,                             /* error.rs:31 */
+  QE_ERR_ARROW = 24,                          /* error.rs:33 */
+  /* Backend-only conditions (no reference counterpart). */
+  QE_ERR_INVALID_ARGUMENT = 40,
+  QE_ERR_DEVICE = 41,        /* a HIP call failed / no gfx950 device */
+  QE_ERR_OUT_OF_MEMORY = 42,
+  QE_ERR_AGG_CAPACITY = 43,  /* group table full even after growth */
+  QE_ERR_INTERNAL = 44
+};
+
+/* Column element types.  INT32/FLOAT64/UTF8/BOOLEAN are the four the
+ * reference's ColumnExpression accepts (physical_expressions.rs:37-60);
+ * INT64 is the extension the north-star configs use. */
+enum {
+  QE_TYPE_INT32 = 1,
+  QE_TYPE_INT64 = 2,
+  QE_TYPE_FLOAT64 = 3,
+  QE_TYPE_BOOLEAN = 4,
+  QE_TYPE_UTF8 = 5
+};
+
+enum { QE_MEM_HOST = 0, QE_MEM_DEVICE = 1 };
+
+/* Binary operators.  EQ/NEQ: physical_expressions.rs:232-233; ADD..DIV:
+ * physical_expressions.rs:346-349.  GT..OR and MOD exist only logically in the
+ * reference (logical_expression.rs:284-294,342) and are rejected by its
+ * planner (query_planner.rs:82); they are lowered here. */
+enum {
+  QE_OP_EQ = 1, QE_OP_NEQ = 2, QE_OP_GT = 3, QE_OP_GTEQ = 4, QE_OP_LT = 5,
+  QE_OP_LTEQ = 6, QE_OP_AND = 7, QE_OP_OR = 8,
+  QE_OP_ADD = 9, QE_OP_SUB = 10, QE_OP_MUL = 11, QE_OP_DIV = 12, QE_OP_MOD = 13
+};
+
+/* Aggregate functions.  MAX/MIN: physical_expressions.rs:503-504;
+ * SUM/COUNT/AVG are logical-only in the reference
+ * (logical_expression.rs:386-423, stub at physical_expressions.rs:505). */
+enum { QE_AGG_MAX = 1, QE_AGG_MIN = 2, QE_AGG_SUM = 3, QE_AGG_COUNT = 4, QE_AGG_AVG = 5 };
+
+/* Aggregation mode (no reference counterpart: the reference is single
+ * process).  PARTIAL emits mergeable state (one row per local group), FINAL
+ * consumes PARTIAL batches from any number of shards. */
+enum { QE_AGG_MODE_SINGLE = 0, QE_AGG_MODE_PARTIAL = 1, QE_AGG_MODE_FINAL = 2 };
+
+/* Context flags. */
+enum {
+  /* Reproduce physical_expressions.rs:264-268: for Sub/Div/Mod with a scalar
+   * left operand and an array right operand the reference computes
+   * `array OP scalar`.  On by default (drop-in parity). */
+  QE_FLAG_REFERENCE_SCALAR_ARRAY_SWAP = 1
+};
+
+typedef struct qe_context qe_context;
+typedef struct qe_batch qe_batch;
+typedef struct qe_expr qe_expr;
+typedef struct qe_agg_expr qe_agg_expr;
+typedef struct qe_plan qe_plan;
+typedef struct qe_iter qe_iter;
+
+/* One Arrow array, described by raw buffers.  Buffer order follows the Arrow
+ * C data interface (validity, offsets, values). */
+typedef struct qe_column {
+  int32_t type;         /* QE_TYPE_* */
+  int32_t memory_space; /* QE_MEM_* : where the three pointers live */
+  int64_t length;       /* rows */
+  int64_t null_count;   /* 0 when validity == NULL */
+  const void *validity; /* LSB-first bitmap, 1 = valid; NULL = all valid */
+  const void *offsets;  /* UTF8: int32[length+1]; else NULL */
+  const void *values;   /* INT32/INT64/FLOAT64: packed values; BOOLEAN: bitmap; UTF8: bytes */
+  int64_t values_bytes; /* size of the values buffer in bytes */
+} qe_column;
+
+/* ColumnarValue (columnar_value.rs:12-15): Array or Scalar. */
+typedef struct qe_value {
+  int32_t is_scalar;    /* 1: `scalar_*` fields hold the value; 0: `array` */
+  int32_t type;         /* QE_TYPE_* */
+  int32_t scalar_valid; /* 0 = null scalar */
+  int32_t _pad;
+  int64_t scalar_i64;   /* INT32 / INT64 / BOOLEAN (0/1) payload */
+  double scalar_f64;    /* FLOAT64 payload */
+  const char *scalar_utf8; /* UTF8 payload (owned by the value, NUL terminated) */
+  int64_t scalar_utf8_len;
+  qe_batch *array;      /* one-column batch holding the array result */
+} qe_value;
+
+/* ---------------------------------------------------------------- library */
+const char *qe_version(void);
+/* Thread-local text of the last failure on this thread ("" if none). */
+const char *qe_last_error_message(void);
+/* Static name of a status code ("DifferentSizes", ...). */
+const char *qe_status_name(qe_status status);
+/* Number of usable gfx950 devices (0 when none / no driver). */
+int32_t qe_device_count(void);
+
+/* --------------------------------------------------------------- context */
+/* `stream` is a hipStream_t to launch on (NULL = a stream the context makes).
+ * Fails with QE_ERR_DEVICE when `device` is not a usable GPU: there is no CPU
+ * fallback behind this ABI. */
+qe_status qe_context_create(int32_t device, void *stream, qe_context **out);
+qe_status qe_context_set_flags(qe_context *ctx, uint32_t flags);
+qe_status qe_context_synchronize(qe_context *ctx);
+void qe_context_free(qe_context *ctx);
+
+/* ---------------------------------------------------------------- batches */
+/* RecordBatch = arrow2 `Chunk<Arc<dyn Array>>` (physical_plan/mod.rs:32).
+ * The buffers are BORROWED: the caller keeps them alive until the batch and
+ * everything derived zero-copy from it is freed. */
+qe_status qe_batch_import(qe_context *ctx, const qe_column *columns, int32_t n_columns, qe_batch **out);
+qe_status qe_batch_num_rows(const qe_batch *batch, int64_t *out);
+qe_status qe_batch_num_columns(const qe_batch *batch, int32_t *out);
+/* Fills `out` with pointers into the batch's buffers (valid until qe_batch_free). */
+qe_status qe_batch_column(const qe_batch *batch, int32_t index, qe_column *out);
+/* Deep copies across the host link; the result owns its buffers. */
+qe_status qe_batch_to_device(qe_context *ctx, const qe_batch *batch, qe_batch **out);
+qe_status qe_batch_to_host(qe_context *ctx, const qe_batch *batch, qe_batch **out);
+void qe_batch_free(qe_batch *batch);
+
+/* ------------------------------------------------------------ expressions */
+/* ColumnExpression { index } (physical_expressions.rs:26-29). */
+qe_status qe_expr_column(int32_t index, qe_expr **out);
+/* LiteralIntegerExpression::new(i32) (physical_expressions.rs:125-131). */
+qe_status qe_expr_lit_i32(int32_t value, qe_expr **out);
+/* Int64 literal: extension (the reference's integer literal is i32 only). */
+qe_status qe_expr_lit_i64(int64_t value, qe_expr **out);
+/* LiteralFloatExpression::new(f64) (physical_expressions.rs:150-156). */
+qe_status qe_expr_lit_f64(double value, qe_expr **out);
+/* LiteralBoolExpression::new(bool) (physical_expressions.rs:75-81). */
+qe_status qe_expr_lit_bool(int32_t value, qe_expr **out);
+/* LiteralStringExpression::new(String) (physical_expressions.rs:100-106). */
+qe_status qe_expr_lit_utf8(const char *bytes, int64_t len, qe_expr **out);
+/* EqExpression::new .. DivExpression::new (physical_expressions.rs:214-222,
+ * 327-335).  Consumes `left` and `right` (Box ownership in the reference). */
+qe_status qe_expr_binary(int32_t op, qe_expr *left, qe_expr *right, qe_expr **out);
+/* Deep copy (the reference's expression structs are Clone/owned). */
+qe_status qe_expr_clone(const qe_expr *expr, qe_expr **out);
+/* `impl Display` (physical_expressions.rs:64-68,225-229,338-342): writes a NUL
+ * terminated string, returns the untruncated length via `needed`. */
+qe_status qe_expr_to_string(const qe_expr *expr, char *buf, int64_t buf_len, int64_t *needed);
+/* PhysicalExpression::evaluate(&Chunk) -> Result<ColumnarValue, Error>
+ * (physical_expressions.rs:22-24).  Borrows expr and batch. */
+qe_status qe_expr_evaluate(qe_context *ctx, const qe_expr *expr, const qe_batch *batch, qe_value *out);
+void qe_value_release(qe_value *value);
+void qe_expr_free(qe_expr *expr);
+
+/* MaxExpression::new / MinExpression::new (physical_expressions.rs:489-493)
+ * plus SUM/COUNT/AVG.  Consumes `input`.  COUNT with input == NULL counts rows
+ * (COUNT(*)). */
+qe_status qe_agg_expr_new(int32_t kind, qe_expr *input, qe_agg_expr **out);
+void qe_agg_expr_free(qe_agg_expr *agg);
+
+/* ------------------------------------------------------------------ plans */
+/* In-memory scan leaf: stands where ScanExec::new(DataSource, projection,
+ * schema) stands (physical_plan/mod.rs:68-110); yields the given batches in
+ * order.  The plan shares (does not copy) the batches' buffers. */
+qe_status qe_plan_scan_memory(qe_context *ctx, qe_batch *const *batches, int32_t n_batches, qe_plan **out);
+/* ProjectionExec::new(input, exprs, schema) (physical_plan/mod.rs:118-130).
+ * Consumes `child` and the expressions. */
+qe_status qe_plan_projection(qe_plan *child, qe_expr *const *exprs, int32_t n_exprs, qe_plan **out);
+/* SelectionExec::new(input, expr, schema) (physical_plan/mod.rs:184-196). */
+qe_status qe_plan_selection(qe_plan *child, qe_expr *predicate, qe_plan **out);
+/* AggregateExec::new(input, group_exprs, agg_exprs, schema)
+ * (physical_plan/mod.rs:258-272).  `mode` is QE_AGG_MODE_*;
+ * `group_capacity_hint` (0 = default) sizes the global group table; the table
+ * grows and the aggregation is re-run when the hint proves too small. */
+qe_status qe_plan_aggregate(qe_plan *child, qe_expr *const *group_exprs, int32_t n_group_exprs,
+                            qe_agg_expr *const *agg_exprs, int32_t n_agg_exprs, int32_t mode,
+                            int64_t group_capacity_hint, qe_plan **out);
+/* `format!("{}", plan)`-style description of the physical plan and of how it
+ * was fused into kernels. */
+qe_status qe_plan_to_string(const qe_plan *plan, char *buf, int64_t buf_len, int64_t *needed);
+/* PhysicalPlan::children (physical_plan/mod.rs:50-57): 0 for a scan, else 1. */
+qe_status qe_plan_num_children(const qe_plan *plan, int32_t *out);
+void qe_plan_free(qe_plan *plan);
+
+/* PhysicalPlan::execute(self) -> Box<dyn Iterator<Item = Batch>>
+ * (physical_plan/mod.rs:58-65).  Consumes the plan. */
+qe_status qe_plan_execute(qe_plan *plan, qe_iter **out);
+/* Iterator::next: QE_OK with a batch, QE_END when exhausted, or an error.
+ * Output batches are device resident and owned by the caller. */
+qe_status qe_iter_next(qe_iter *iter, qe_batch **out);
+void qe_iter_free(qe_iter *iter);
+
+/* ------------------------------------------------- synthetic data (bench) */
+/* Counter-based generator (splitmix64 of row index and seed): fills
+ * device buffers of `n` rows starting at global row `row0`, so any shard is
+ * reproducible on host and device.  kind: 0 = f64 uniform [lo,hi),
+ * 1 = i64 uniform {lo..hi-1} (lo/hi rounded), 2 = i64 zipf(s=hi) over
+ * {0..lo-1}, 3 = i64 skewed passenger-count style key over {0..9}. */
+qe_status qe_generate_column(qe_context *ctx, int32_t kind, uint64_t seed, int64_t row0, int64_t n,
+                             double lo, double hi, void *device_out);
+
+/* Device timing of the kernels the last qe_iter_next / qe_expr_evaluate call
+ * launched on this context: name, launches and total milliseconds measured
+ * with HIP events on the context's stream (enabled by qe_context_profile). */
+qe_status qe_context_profile(qe_context *ctx, int32_t enable);
+qe_status qe_context_profile_read(qe_context *ctx, char *buf, int64_t buf_len, int64_t *needed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QE_GPU_H */

@@ -1,0 +1,168 @@
+// Host-side object model of the backend: context + device memory pool, Arrow
+// column/batch containers, expression trees.  Mirrors the reference's value
+// model (columnar_value.rs) and expression structs (physical_expressions.rs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/qe_gpu.h"
+#include "qe_kernels.h"
+
+namespace qe {
+
+struct Failure {
+  qe_status code;
+  std::string msg;
+};
+[[noreturn]] void fail(qe_status code, const std::string &msg);
+void hip_check(hipError_t e, const char *what);
+#define QE_HIP(expr) ::qe::hip_check((expr), #expr)
+
+struct Context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  uint32_t flags = QE_FLAG_REFERENCE_SCALAR_ARRAY_SWAP;
+  DeviceInfo dev{};
+  // size-bucketed free lists: hipMalloc/hipFree are far too slow to call per batch
+  std::map<size_t, std::vector<void *>> pool;
+  size_t pool_bytes = 0;
+  void *filter_scratch = nullptr;
+  size_t filter_scratch_cap = 0;
+  unsigned long long *counters = nullptr;  // small device scratch for counts
+  unsigned long long *host_counters = nullptr;  // pinned mirror
+  // profiling
+  bool profiling = false;
+  struct LaunchRec {
+    const char *name;
+    hipEvent_t start, stop;
+  };
+  std::vector<LaunchRec> launches;
+
+  void *alloc(size_t bytes, size_t *actual);
+  void release(void *p, size_t actual);
+  void bind() const;
+  void sync() const;
+  void prof_begin(const char *name);
+  void prof_end();
+  ~Context();
+};
+
+struct Buffer {
+  Context *ctx = nullptr;
+  void *ptr = nullptr;
+  size_t bytes = 0;   // usable bytes
+  size_t actual = 0;  // pool bucket size (device, owned)
+  int space = QE_MEM_HOST;
+  bool owned = false;
+  ~Buffer();
+};
+using BufferPtr = std::shared_ptr<Buffer>;
+
+BufferPtr device_buffer(Context *ctx, size_t bytes);
+BufferPtr host_buffer(size_t bytes);
+BufferPtr borrowed_buffer(const void *p, size_t bytes, int space);
+
+struct Column {
+  int type = 0;
+  int space = QE_MEM_DEVICE;
+  int64_t length = 0;
+  int64_t null_count = 0;  // -1 = not counted yet
+  BufferPtr validity, offsets, values;
+  int64_t values_bytes = 0;
+  const void *values_ptr() const { return values ? values->ptr : nullptr; }
+  const uint8_t *validity_ptr() const { return validity ? (const uint8_t *)validity->ptr : nullptr; }
+  const int32_t *offsets_ptr() const { return offsets ? (const int32_t *)offsets->ptr : nullptr; }
+};
+
+struct Batch {
+  Context *ctx = nullptr;
+  std::vector<Column> cols;
+  int64_t rows = 0;
+};
+
+size_t bitmap_bytes(int64_t n);   // padded to whole 32-byte groups
+int type_width(int type);         // bytes per value of a fixed-width type (0 otherwise)
+const char *type_name(int type);
+
+// ------------------------------------------------------------- expressions
+enum ExprKind { EK_COLUMN = 0, EK_LITERAL = 1, EK_BINARY = 2 };
+
+struct Expr;
+using ExprPtr = std::shared_ptr<const Expr>;
+
+struct Expr {
+  ExprKind kind = EK_COLUMN;
+  int index = 0;       // EK_COLUMN
+  int type = 0;        // EK_LITERAL: QE_TYPE_*
+  bool valid = true;   // EK_LITERAL: false = null scalar
+  int64_t ival = 0;    // INT32 / INT64 / BOOLEAN payload
+  double fval = 0.0;   // FLOAT64 payload
+  std::string sval;    // UTF8 payload
+  int op = 0;          // EK_BINARY: QE_OP_*
+  bool to_f64 = false; // EK_BINARY unused; internal cast marker (AVG over integers)
+  ExprPtr l, r;
+};
+
+struct AggExpr {
+  int kind = 0;   // QE_AGG_*
+  ExprPtr input;  // may be null for COUNT(*)
+};
+
+ExprPtr make_column(int index);
+ExprPtr make_lit_i32(int32_t v);
+ExprPtr make_lit_i64(int64_t v);
+ExprPtr make_lit_f64(double v);
+ExprPtr make_lit_bool(bool v);
+ExprPtr make_lit_utf8(const std::string &s);
+ExprPtr make_binary(int op, ExprPtr l, ExprPtr r);
+std::string expr_to_string(const ExprPtr &e);
+bool expr_is_scalar(const ExprPtr &e);
+
+struct ColInfo {
+  int type;
+  bool nullable;
+};
+using Schema = std::vector<ColInfo>;
+Schema schema_of(const Batch &b);
+
+// Type of the value an expression evaluates to over `schema`; throws the
+// reference's error for out-of-range columns / unsupported operand types.
+int expr_type(const ExprPtr &e, const Schema &schema);
+bool expr_nullable(const ExprPtr &e, const Schema &schema);
+// Folds every column-free subtree into a literal with the semantics of the
+// reference's (Scalar, Scalar) arms (physical_expressions.rs:204-208,269-321)
+// and applies the (Scalar, Array) operand swap when `flags` asks for it.
+ExprPtr expr_normalize(const ExprPtr &e, uint32_t flags);
+// Replace Column(i) by outputs[i].
+ExprPtr expr_substitute(const ExprPtr &e, const std::vector<ExprPtr> &outputs);
+
+// ----------------------------------------------------- expression compiler
+struct Compiler {
+  Context *ctx;
+  const Batch *batch;
+  Schema schema;
+  VmProgram prog{};
+  int n_insn = 0, n_lits = 0, n_cols = 0;
+  std::map<int, int> colmap;           // batch column -> program column
+  std::vector<BufferPtr> keepalive;    // device copies of utf8 literals
+  Compiler(Context *c, const Batch *b);
+  // Space check before adding an expression: worst-case instruction / literal / column needs.
+  bool fits(const ExprPtr &e) const;
+  // Emits code ending in OP_END, returns the start pc.
+  uint32_t add(const ExprPtr &e);
+  uint32_t add_rowid();
+ private:
+  int need(const ExprPtr &e) const;
+  void emit(const ExprPtr &e, int depth);
+  int col_slot(int index);
+  int lit_slot(uint64_t bits);
+  void push_insn(uint32_t op, uint32_t depth, uint32_t arg);
+};
+
+}  // namespace qe

@@ -1,0 +1,1261 @@
+// Physical operators (Scan / Projection / Selection / Aggregate) as pull
+// iterators over device-resident batches, the fusion of operator chains into
+// single kernel launches, and the extern "C" boundary.
+//
+// Reference shape being mirrored: PhysicalPlan::execute(self) returns a boxed
+// iterator of batches (physical_plan/mod.rs:58-65); each *Exec pops its single
+// child (:167-170, :240-243, :293-296); Aggregate is eager and yields exactly
+// one batch (:274-283).
+#include <algorithm>
+#include <cstring>
+#include <sstream>
+
+#include "qe_core.h"
+
+namespace qe {
+
+// ---------------------------------------------------------------- iterators
+struct Iter {
+  virtual ~Iter() {}
+  virtual bool next(Batch &out) = 0;  // false = exhausted
+  virtual void reset() = 0;           // start over (used when a group table has to grow)
+};
+
+struct ScanIter : Iter {
+  std::vector<Batch> batches;
+  size_t cur = 0;
+  bool next(Batch &out) override {
+    if (cur >= batches.size()) return false;
+    out = batches[cur++];
+    return true;
+  }
+  void reset() override { cur = 0; }
+};
+
+// A run of Projection / Selection operators over one source, expressed over the
+// source's columns so that the whole run is one kernel per batch.
+struct Stream {
+  std::unique_ptr<Iter> src;
+  bool identity = true;          // outputs == source columns
+  std::vector<ExprPtr> outputs;  // valid when !identity
+  ExprPtr pred;                  // conjunction of every Selection below
+};
+
+static std::vector<ExprPtr> stream_outputs(const Stream &s, int n_source_cols) {
+  if (!s.identity) return s.outputs;
+  std::vector<ExprPtr> o;
+  for (int i = 0; i < n_source_cols; ++i) o.push_back(make_column(i));
+  return o;
+}
+
+static Column make_fixed_column(Context *ctx, int type, int64_t capacity_rows, bool with_validity, bool zero_values) {
+  Column c;
+  c.type = type;
+  c.space = QE_MEM_DEVICE;
+  size_t vb = type == QE_TYPE_BOOLEAN ? bitmap_bytes(capacity_rows) : (size_t)capacity_rows * type_width(type) + 16;
+  c.values = device_buffer(ctx, vb);
+  c.values_bytes = (int64_t)vb;
+  if (type == QE_TYPE_BOOLEAN || zero_values) QE_HIP(hipMemsetAsync(c.values->ptr, 0, vb, ctx->stream));
+  if (with_validity) {
+    size_t bb = bitmap_bytes(capacity_rows);
+    c.validity = device_buffer(ctx, bb);
+    QE_HIP(hipMemsetAsync(c.validity->ptr, 0, bb, ctx->stream));
+    c.null_count = -1;
+  }
+  return c;
+}
+
+static void finish_fixed_column(Column &c, int64_t rows) {
+  c.length = rows;
+  if (c.type != QE_TYPE_BOOLEAN) c.values_bytes = rows * type_width(c.type);
+  else c.values_bytes = (rows + 7) / 8;
+}
+
+static uint8_t vm_type_of(int t) { return (uint8_t)t; }  // QE_TYPE_* and VmType share values
+
+static void ensure_filter_scratch(Context *ctx, int64_t n_rows) {
+  size_t need = filter_scratch_bytes(n_rows);
+  if (need > ctx->filter_scratch_cap) {
+    ctx->sync();
+    if (ctx->filter_scratch) QE_HIP(hipFree(ctx->filter_scratch));
+    size_t cap = need * 2;
+    QE_HIP(hipMalloc(&ctx->filter_scratch, cap));
+    ctx->filter_scratch_cap = cap;
+  }
+}
+
+static void ensure_counters(Context *ctx) {
+  if (!ctx->counters) {
+    QE_HIP(hipMalloc((void **)&ctx->counters, 64 * sizeof(unsigned long long)));
+    QE_HIP(hipHostMalloc((void **)&ctx->host_counters, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+  }
+}
+
+static Column utf8_broadcast_column(Context *ctx, const std::string &s, int64_t rows) {
+  if ((double)rows * (double)s.size() > 2147483647.0)
+    fail(QE_ERR_ARROW, "utf8 broadcast exceeds int32 offsets");
+  Column c;
+  c.type = QE_TYPE_UTF8;
+  c.space = QE_MEM_DEVICE;
+  c.length = rows;
+  c.offsets = device_buffer(ctx, (size_t)(rows + 1) * 4);
+  c.values_bytes = rows * (int64_t)s.size();
+  c.values = device_buffer(ctx, (size_t)c.values_bytes + 16);
+  BufferPtr lit = device_buffer(ctx, s.size() + 1);
+  QE_HIP(hipMemcpyAsync(lit->ptr, s.data(), s.size(), hipMemcpyHostToDevice, ctx->stream));
+  ctx->prof_begin("qe_utf8_broadcast_kernel");
+  QE_HIP(launch_utf8_broadcast((const uint8_t *)lit->ptr, (int32_t)s.size(), rows, (int32_t *)c.offsets->ptr,
+                               (uint8_t *)c.values->ptr, ctx->stream));
+  ctx->prof_end();
+  ctx->sync();  // `lit` is released on return
+  return c;
+}
+
+static Column utf8_gather_column(Context *ctx, const Column &src, const int64_t *idx, int64_t m) {
+  Column c;
+  c.type = QE_TYPE_UTF8;
+  c.space = QE_MEM_DEVICE;
+  c.length = m;
+  c.offsets = device_buffer(ctx, (size_t)(m + 1) * 4 + 16);
+  if (src.validity) {
+    size_t bb = bitmap_bytes(m);
+    c.validity = device_buffer(ctx, bb);
+    QE_HIP(hipMemsetAsync(c.validity->ptr, 0, bb, ctx->stream));
+    c.null_count = -1;
+  }
+  int32_t *offs = (int32_t *)c.offsets->ptr;
+  // lengths -> offs[0..m), then exclusive scan over m+1 entries gives offs[m] = total
+  QE_HIP(hipMemsetAsync(offs + m, 0, 4, ctx->stream));
+  ctx->prof_begin("qe_utf8_gather_lengths_kernel");
+  QE_HIP(launch_utf8_gather_lengths(src.offsets_ptr(), src.validity_ptr(), idx, m, offs,
+                                    c.validity ? (uint32_t *)c.validity->ptr : nullptr, ctx->stream));
+  ctx->prof_end();
+  BufferPtr scan_tmp = device_buffer(ctx, scan_scratch_elems(m + 1) * 4 + 64);
+  ctx->prof_begin("qe_scan_kernels");
+  QE_HIP(launch_exclusive_scan_i32(offs, m + 1, (int32_t *)scan_tmp->ptr, ctx->stream));
+  ctx->prof_end();
+  ensure_counters(ctx);
+  QE_HIP(hipMemcpyAsync(ctx->host_counters + 8, offs + m, 4, hipMemcpyDeviceToHost, ctx->stream));
+  ctx->sync();
+  int32_t total = *(int32_t *)(ctx->host_counters + 8);
+  c.values_bytes = total;
+  c.values = device_buffer(ctx, (size_t)total + 16);
+  ctx->prof_begin("qe_utf8_gather_bytes_kernel");
+  QE_HIP(launch_utf8_gather_bytes(src.offsets_ptr(), (const uint8_t *)src.values_ptr(), idx, m, offs,
+                                  (uint8_t *)c.values->ptr, ctx->stream));
+  ctx->prof_end();
+  return c;
+}
+
+// Evaluates `outputs` (expressions over `in`'s columns) for the rows of `in`
+// that satisfy `pred` (all rows when null).  ProjectionIterator::next
+// (physical_plan/mod.rs:138-156) and SelectionIterator::next (:205-229) fused.
+static Batch run_pipeline(Context *ctx, const Batch &in, const std::vector<ExprPtr> &outputs_raw, const ExprPtr &pred_raw) {
+  ctx->bind();
+  const int64_t n = in.rows;
+  Schema schema = schema_of(in);
+  std::vector<ExprPtr> outs;
+  for (auto &e : outputs_raw) outs.push_back(expr_normalize(e, ctx->flags));
+  ExprPtr pred = pred_raw ? expr_normalize(pred_raw, ctx->flags) : nullptr;
+  std::vector<int> types;
+  for (auto &e : outs) types.push_back(expr_type(e, schema));
+  if (pred) {
+    // Selection needs a BooleanArray (physical_plan/mod.rs:215-218)
+    if (expr_type(pred, schema) != QE_TYPE_BOOLEAN)
+      fail(QE_ERR_NO_BOOLEAN_ARRAY_FOR_FILTER, "Expr doesn't evaluate to a boolean array, which is needed to filter.");
+    if (pred->kind == EK_LITERAL && !pred->valid)
+      fail(QE_ERR_SCALAR_TO_ARRAY, "Couldn't convert Scalar value `null` to array.");
+  }
+  for (auto &e : outs)
+    if (e->kind == EK_LITERAL && !e->valid)
+      fail(QE_ERR_SCALAR_TO_ARRAY, "Couldn't convert Scalar value `null` to array.");  // columnar_value.rs:33
+
+  Batch out;
+  out.ctx = ctx;
+  out.cols.resize(outs.size());
+
+  if (!pred) {
+    out.rows = n;
+    std::vector<int> vm_list;
+    for (size_t i = 0; i < outs.size(); ++i) {
+      const ExprPtr &e = outs[i];
+      if (e->kind == EK_COLUMN) {
+        out.cols[i] = in.cols[e->index];  // Arc clone in the reference (physical_expressions.rs:41)
+      } else if (e->kind == EK_LITERAL && e->type == QE_TYPE_UTF8) {
+        out.cols[i] = utf8_broadcast_column(ctx, e->sval, n);
+      } else {
+        if (types[i] == QE_TYPE_UTF8) fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "Physical type `Utf8` is not supported in a computed expression.");
+        vm_list.push_back((int)i);
+      }
+    }
+    size_t k = 0;
+    while (k < vm_list.size()) {
+      Compiler comp(ctx, &in);
+      ProjectArgs args{};
+      int cnt = 0;
+      while (k < vm_list.size() && cnt < VM_MAX_OUTS && (cnt == 0 || comp.fits(outs[vm_list[k]]))) {
+        int i = vm_list[k];
+        bool nullable = expr_nullable(outs[i], schema);
+        Column c = make_fixed_column(ctx, types[i], n, nullable, false);
+        finish_fixed_column(c, n);
+        VmOut &o = args.outs[cnt];
+        o.pc = comp.add(outs[i]);
+        o.type = vm_type_of(types[i]);
+        o.values = c.values->ptr;
+        o.validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
+        out.cols[i] = c;
+        ++cnt;
+        ++k;
+      }
+      args.prog = comp.prog;
+      args.n_outs = cnt;
+      args.n_rows = n;
+      ctx->prof_begin("qe_project_kernel");
+      QE_HIP(launch_project(args, ctx->dev, ctx->stream));
+      ctx->prof_end();
+      if (!comp.keepalive.empty()) ctx->sync();
+    }
+    return out;
+  }
+
+  // ---- filtered
+  std::vector<int> vm_list, utf8_cols, utf8_lits;
+  for (size_t i = 0; i < outs.size(); ++i) {
+    const ExprPtr &e = outs[i];
+    if (types[i] == QE_TYPE_UTF8) {
+      if (e->kind == EK_COLUMN) utf8_cols.push_back((int)i);
+      else if (e->kind == EK_LITERAL) utf8_lits.push_back((int)i);
+      else fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "Physical type `Utf8` is not supported in a computed expression.");
+    } else {
+      vm_list.push_back((int)i);
+    }
+  }
+  ensure_filter_scratch(ctx, n);
+  ensure_counters(ctx);
+  FilterScratch *scratch = (FilterScratch *)ctx->filter_scratch;
+  int64_t m = 0;
+  Column rowid;
+  bool need_rowid = !utf8_cols.empty();
+  size_t k = 0;
+  bool first = true;
+  while (first || k < vm_list.size()) {
+    Compiler comp(ctx, &in);
+    FilterArgs args{};
+    args.pred_pc = comp.add(pred);
+    int cnt = 0;
+    if (first && need_rowid) {
+      rowid = make_fixed_column(ctx, QE_TYPE_INT64, n, false, false);
+      VmOut &o = args.outs[cnt++];
+      o.pc = comp.add_rowid();
+      o.type = VT_I64;
+      o.values = rowid.values->ptr;
+      o.validity = nullptr;
+    }
+    while (k < vm_list.size() && cnt < VM_MAX_OUTS && comp.fits(outs[vm_list[k]])) {
+      int i = vm_list[k];
+      bool nullable = expr_nullable(outs[i], schema);
+      Column c = make_fixed_column(ctx, types[i], n, nullable, false);
+      VmOut &o = args.outs[cnt];
+      o.pc = comp.add(outs[i]);
+      o.type = vm_type_of(types[i]);
+      o.values = c.values->ptr;
+      o.validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
+      out.cols[i] = c;
+      ++cnt;
+      ++k;
+    }
+    if (!first && cnt == 0) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression is too long for one kernel.");
+    args.prog = comp.prog;
+    args.n_outs = cnt;
+    args.n_rows = n;
+    args.n_tiles = filter_num_tiles(n);
+    args.scratch = scratch;
+    QE_HIP(launch_filter_reset(scratch, n, ctx->stream));
+    ctx->prof_begin("qe_filter_kernel");
+    QE_HIP(launch_filter(args, ctx->dev, ctx->stream));
+    ctx->prof_end();
+    if (first) {
+      QE_HIP(hipMemcpyAsync(ctx->host_counters, scratch, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+      ctx->sync();
+      if (ctx->host_counters[2] != 0) fail(QE_ERR_INTERNAL, "filter look-back timed out");
+      m = n > 0 ? (int64_t)ctx->host_counters[1] : 0;
+    } else if (!comp.keepalive.empty()) {
+      ctx->sync();
+    }
+    first = false;
+  }
+  out.rows = m;
+  for (int i : vm_list) finish_fixed_column(out.cols[i], m);
+  for (int i : utf8_cols) out.cols[i] = utf8_gather_column(ctx, in.cols[outs[i]->index], (const int64_t *)rowid.values->ptr, m);
+  for (int i : utf8_lits) out.cols[i] = utf8_broadcast_column(ctx, outs[i]->sval, m);
+  if (need_rowid) ctx->sync();  // rowid buffer goes back to the pool on return
+  return out;
+}
+
+struct PipeIter : Iter {
+  Context *ctx;
+  Stream s;
+  bool next(Batch &out) override {
+    Batch in;
+    if (!s.src->next(in)) return false;
+    if (s.identity && !s.pred) {
+      out = in;
+      return true;
+    }
+    out = run_pipeline(ctx, in, stream_outputs(s, (int)in.cols.size()), s.pred);
+    return true;
+  }
+  void reset() override { s.src->reset(); }
+};
+
+// ---------------------------------------------------------------- aggregate
+struct AccDesc {
+  VmAcc acc{};
+  ExprPtr input;
+};
+struct AggSpec {
+  std::vector<VmKey> keys;
+  std::vector<ExprPtr> key_exprs;
+  std::vector<AccDesc> accs;
+  std::vector<FinOut> outs;  // pointers filled at finalize time
+};
+
+static int add_acc(AggSpec &spec, uint8_t op, int in_type, bool track_nn, const ExprPtr &input) {
+  if ((int)spec.accs.size() >= VM_MAX_ACCS)
+    fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many aggregate accumulators for one kernel.");
+  AccDesc d;
+  d.acc.op = op;
+  d.acc.in_type = (uint8_t)in_type;
+  d.acc.track_nn = track_nn ? 1 : 0;
+  d.acc.has_input = input ? 1 : 0;
+  d.input = input;
+  spec.accs.push_back(d);
+  return (int)spec.accs.size() - 1;
+}
+
+static FinOut fin(uint8_t kind, int type, int a, int b, uint8_t cnt_src, uint8_t null_mode) {
+  FinOut f{};
+  f.kind = kind;
+  f.type = (uint8_t)type;
+  f.a = (int8_t)a;
+  f.b = (int8_t)b;
+  f.cnt_src = cnt_src;
+  f.null_mode = null_mode;
+  return f;
+}
+
+static ExprPtr make_to_f64(const ExprPtr &e) {
+  auto n = std::make_shared<Expr>();
+  n->kind = EK_BINARY;
+  n->to_f64 = true;
+  n->l = e;
+  return n;
+}
+
+static bool numeric(int t) { return t == QE_TYPE_INT32 || t == QE_TYPE_INT64 || t == QE_TYPE_FLOAT64; }
+
+static AggSpec build_agg_spec(Context *ctx, const Schema &schema, const std::vector<ExprPtr> &groups,
+                              const std::vector<AggExpr> &aggs, const std::vector<ExprPtr> &aggs_second, int mode) {
+  AggSpec spec;
+  int shift = 0;
+  if ((int)groups.size() > VM_MAX_KEYS) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many group expressions.");
+  for (size_t g = 0; g < groups.size(); ++g) {
+    ExprPtr e = expr_normalize(groups[g], ctx->flags);
+    int t = expr_type(e, schema);
+    int bits = t == QE_TYPE_INT32 ? 32 : t == QE_TYPE_INT64 ? 64 : t == QE_TYPE_BOOLEAN ? 1 : 0;
+    // arrow2 cannot hash floats (the reference unwrap()s: physical_plan/mod.rs:317); utf8 keys are not lowered yet
+    if (bits == 0) fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, std::string("Physical type `") + type_name(t) + "` is not supported as a group key.");
+    if (shift + bits > 64) fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "Group key wider than 64 bits is not supported.");
+    VmKey k{};
+    k.type = (uint8_t)t;
+    k.shift = (uint8_t)shift;
+    k.bits = (uint8_t)bits;
+    spec.keys.push_back(k);
+    spec.key_exprs.push_back(e);
+    FinOut f = fin(FIN_KEY, t, (int)g, 0, CNT_ROWS, NULL_NEVER);
+    f.shift = (uint8_t)shift;
+    f.bits = (uint8_t)bits;
+    spec.outs.push_back(f);
+    shift += bits;
+  }
+  for (size_t i = 0; i < aggs.size(); ++i) {
+    const AggExpr &ag = aggs[i];
+    ExprPtr e = ag.input ? expr_normalize(ag.input, ctx->flags) : nullptr;
+    int t = e ? expr_type(e, schema) : 0;
+    bool nullable = e ? expr_nullable(e, schema) : false;
+    if (e && e->kind == EK_LITERAL && !e->valid) fail(QE_ERR_SCALAR_TO_ARRAY, "Couldn't convert Scalar value `null` to array.");
+    auto need_numeric = [&]() {
+      if (!e || !numeric(t))
+        fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, std::string("Physical type `") + (e ? type_name(t) : "none") + "` is not supported.");
+    };
+    bool final_mode = mode == QE_AGG_MODE_FINAL;
+    switch (ag.kind) {
+      case QE_AGG_MAX:
+      case QE_AGG_MIN: {
+        need_numeric();
+        bool is_min = ag.kind == QE_AGG_MIN;
+        bool f64 = t == QE_TYPE_FLOAT64;
+        int a = add_acc(spec, is_min ? ACC_MIN : ACC_MAX, t, nullable && !f64, e);
+        uint8_t nm = f64 ? (is_min ? NULL_IF_ACC_ALL_ONES : NULL_IF_ACC_ZERO) : (nullable ? NULL_IF_COUNT_ZERO : NULL_NEVER);
+        spec.outs.push_back(fin(FIN_ACC_ORD, t, a, a, CNT_NN, nm));
+        break;
+      }
+      case QE_AGG_SUM: {
+        need_numeric();
+        bool f64 = t == QE_TYPE_FLOAT64;
+        int a = add_acc(spec, f64 ? ACC_SUM_F64 : ACC_SUM_I64, t, nullable, e);
+        spec.outs.push_back(fin(f64 ? FIN_ACC_F64 : FIN_ACC_I64, t, a, a, CNT_NN, nullable ? NULL_IF_COUNT_ZERO : NULL_NEVER));
+        break;
+      }
+      case QE_AGG_COUNT: {
+        if (final_mode) {
+          if (!e || t != QE_TYPE_INT64) fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "COUNT partial column must be Int64.");
+          int a = add_acc(spec, ACC_SUM_I64, t, false, e);
+          spec.outs.push_back(fin(FIN_ACC_I64, QE_TYPE_INT64, a, a, CNT_ROWS, NULL_NEVER));
+        } else if (!e || !nullable) {
+          spec.outs.push_back(fin(FIN_COUNT, QE_TYPE_INT64, 0, 0, CNT_ROWS, NULL_NEVER));
+        } else {
+          int a = add_acc(spec, ACC_COUNT, t, false, e);
+          spec.outs.push_back(fin(FIN_COUNT, QE_TYPE_INT64, a, a, CNT_ACC, NULL_NEVER));
+        }
+        break;
+      }
+      case QE_AGG_AVG: {
+        if (final_mode) {
+          ExprPtr cnt_e = aggs_second[i] ? expr_normalize(aggs_second[i], ctx->flags) : nullptr;
+          if (!e || t != QE_TYPE_FLOAT64 || !cnt_e || expr_type(cnt_e, schema) != QE_TYPE_INT64)
+            fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "AVG partial columns must be (Float64 sum, Int64 count).");
+          int a = add_acc(spec, ACC_SUM_F64, QE_TYPE_FLOAT64, false, e);
+          int b = add_acc(spec, ACC_SUM_I64, QE_TYPE_INT64, false, cnt_e);
+          spec.outs.push_back(fin(FIN_AVG, QE_TYPE_FLOAT64, a, b, CNT_ACC, NULL_IF_COUNT_ZERO));
+          break;
+        }
+        need_numeric();
+        int a = add_acc(spec, ACC_SUM_F64, QE_TYPE_FLOAT64, false, make_to_f64(e));
+        int b = -1;
+        uint8_t src = CNT_ROWS;
+        if (nullable) {
+          b = add_acc(spec, ACC_COUNT, t, false, e);
+          src = CNT_ACC;
+        }
+        if (mode == QE_AGG_MODE_PARTIAL) {
+          spec.outs.push_back(fin(FIN_ACC_F64, QE_TYPE_FLOAT64, a, a, CNT_ROWS, NULL_NEVER));
+          spec.outs.push_back(fin(FIN_COUNT, QE_TYPE_INT64, b < 0 ? 0 : b, b < 0 ? 0 : b, src, NULL_NEVER));
+        } else {
+          spec.outs.push_back(fin(FIN_AVG, QE_TYPE_FLOAT64, a, b < 0 ? 0 : b, src, NULL_IF_COUNT_ZERO));
+        }
+        break;
+      }
+      default:
+        fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression `aggregate` is not supported.");
+    }
+  }
+  return spec;
+}
+
+struct AggIter : Iter {
+  Context *ctx;
+  Stream s;
+  std::vector<ExprPtr> groups;  // over the child's output columns
+  std::vector<AggExpr> aggs;
+  int mode = QE_AGG_MODE_SINGLE;
+  int64_t cap_hint = 0;
+  bool done = false, yielded = false;
+  Batch result;
+
+  void compute() {
+    ctx->bind();
+    ensure_counters(ctx);
+    int64_t hint = cap_hint > 0 ? cap_hint : 32768;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+      uint64_t cap = 1024;
+      while (cap < (uint64_t)hint * 2) cap <<= 1;
+      if (cap > (1ull << 30)) fail(QE_ERR_AGG_CAPACITY, "group table would exceed 2^30 slots");
+      s.src->reset();
+      bool have_table = false;
+      AggSpec spec;
+      AggTable table{};
+      BufferPtr table_buf;
+      std::vector<int> key_types, acc_types;
+      Batch in;
+      while (s.src->next(in)) {
+        int ncols = (int)in.cols.size();
+        std::vector<ExprPtr> src_outs = stream_outputs(s, ncols);
+        std::vector<ExprPtr> g2;
+        std::vector<AggExpr> a2;
+        std::vector<ExprPtr> a2_second;
+        for (auto &g : groups) g2.push_back(expr_substitute(g, src_outs));
+        for (auto &a : aggs) {
+          AggExpr x;
+          x.kind = a.kind;
+          x.input = a.input ? expr_substitute(a.input, src_outs) : nullptr;
+          a2.push_back(x);
+          ExprPtr second;
+          if (mode == QE_AGG_MODE_FINAL && a.kind == QE_AGG_AVG && a.input && a.input->kind == EK_COLUMN)
+            second = expr_substitute(make_column(a.input->index + 1), src_outs);
+          a2_second.push_back(second);
+        }
+        Schema schema = schema_of(in);
+        AggSpec bspec = build_agg_spec(ctx, schema, g2, a2, a2_second, mode);
+        if (!have_table) {
+          spec = bspec;
+          int na = (int)spec.accs.size();
+          table.cap = cap;
+          table.stride = (cap + 1 + 63) & ~63ull;
+          size_t words = table.stride * (2 + 2 * (size_t)na) + 8;
+          table_buf = device_buffer(ctx, words * 8);
+          unsigned long long *base = (unsigned long long *)table_buf->ptr;
+          table.keys = base;
+          table.rowcnt = base + table.stride;
+          table.acc = base + 2 * table.stride;
+          table.nn = table.acc + (size_t)na * table.stride;
+          table.ctrl = table.nn + (size_t)na * table.stride;
+          std::vector<VmAcc> va;
+          for (auto &d : spec.accs) va.push_back(d.acc);
+          ctx->prof_begin("qe_table_init_kernel");
+          QE_HIP(launch_table_init(table, va.data(), na, ctx->stream));
+          ctx->prof_end();
+          have_table = true;
+        } else {
+          bool same = bspec.accs.size() == spec.accs.size() && bspec.keys.size() == spec.keys.size();
+          for (size_t i = 0; same && i < spec.accs.size(); ++i)
+            same = bspec.accs[i].acc.op == spec.accs[i].acc.op && bspec.accs[i].acc.in_type == spec.accs[i].acc.in_type;
+          for (size_t i = 0; same && i < spec.keys.size(); ++i) same = bspec.keys[i].type == spec.keys[i].type;
+          if (!same) fail(QE_ERR_INVALID_ARGUMENT, "batches of one scan must share a schema");
+          // a later batch may be nullable where the first was not: keep the stricter tracking
+          for (size_t i = 0; i < spec.accs.size(); ++i)
+            if (bspec.accs[i].acc.track_nn && !spec.accs[i].acc.track_nn)
+              fail(QE_ERR_INVALID_ARGUMENT, "batches of one scan must share nullability");
+        }
+        if (in.rows == 0) continue;
+        Compiler comp(ctx, &in);
+        AggArgs args{};
+        ExprPtr pred = s.pred ? expr_normalize(s.pred, ctx->flags) : nullptr;
+        if (pred) {
+          if (expr_type(pred, schema) != QE_TYPE_BOOLEAN)
+            fail(QE_ERR_NO_BOOLEAN_ARRAY_FOR_FILTER, "Expr doesn't evaluate to a boolean array, which is needed to filter.");
+          args.has_pred = 1;
+          args.pred_pc = comp.add(pred);
+        }
+        for (size_t i = 0; i < bspec.keys.size(); ++i) {
+          args.keys[i] = bspec.keys[i];
+          args.keys[i].pc = comp.add(bspec.key_exprs[i]);
+        }
+        for (size_t i = 0; i < bspec.accs.size(); ++i) {
+          args.accs[i] = bspec.accs[i].acc;
+          args.accs[i].track_nn = spec.accs[i].acc.track_nn;
+          if (bspec.accs[i].input) args.accs[i].pc = comp.add(bspec.accs[i].input);
+        }
+        args.prog = comp.prog;
+        args.table = table;
+        args.n_keys = (int)bspec.keys.size();
+        args.n_accs = (int)bspec.accs.size();
+        args.n_rows = in.rows;
+        args.lds_cap = aggregate_lds_slots(args.n_accs, ctx->dev);
+        args.lds_limit = args.lds_cap - args.lds_cap / 4;
+        ctx->prof_begin("qe_aggregate_kernel");
+        QE_HIP(launch_aggregate(args, ctx->dev, ctx->stream));
+        ctx->prof_end();
+        if (!comp.keepalive.empty()) ctx->sync();
+      }
+      // empty input: `iter.next().ok_or(Error::EmptyHashmapForAggregate)` (physical_plan/mod.rs:377)
+      if (!have_table) fail(QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE, "The hashmap for aggregation is empty.");
+      QE_HIP(hipMemcpyAsync(ctx->host_counters + 16, table.ctrl, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+      ctx->sync();
+      unsigned long long n_groups = ctx->host_counters[16], overflow = ctx->host_counters[17];
+      if (overflow) {
+        hint = (int64_t)cap * 4;  // grow and run the aggregation again
+        continue;
+      }
+      if (n_groups == 0) fail(QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE, "The hashmap for aggregation is empty.");
+      // output assembly (physical_plan/mod.rs:375-488): key columns, then one column per aggregate
+      FinalizeArgs fa{};
+      fa.table = table;
+      fa.n_outs = (int)spec.outs.size();
+      result = Batch();
+      result.ctx = ctx;
+      result.rows = (int64_t)n_groups;
+      for (size_t i = 0; i < spec.outs.size(); ++i) {
+        FinOut f = spec.outs[i];
+        Column c = make_fixed_column(ctx, f.type, (int64_t)n_groups, f.null_mode != NULL_NEVER, false);
+        finish_fixed_column(c, (int64_t)n_groups);
+        f.values = c.values->ptr;
+        f.validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
+        fa.outs[i] = f;
+        result.cols.push_back(c);
+      }
+      QE_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
+      fa.out_count = ctx->counters;
+      ctx->prof_begin("qe_finalize_kernel");
+      QE_HIP(launch_finalize(fa, ctx->stream));
+      ctx->prof_end();
+      ctx->sync();
+      done = true;
+      return;
+    }
+    fail(QE_ERR_AGG_CAPACITY, "group table still full after growing");
+  }
+
+  bool next(Batch &out) override {
+    if (!done) compute();
+    if (yielded) return false;
+    yielded = true;
+    out = result;
+    return true;
+  }
+  void reset() override { yielded = false; }
+};
+
+// -------------------------------------------------------------------- plans
+enum PlanKind { PK_SCAN = 0, PK_PROJECTION = 1, PK_SELECTION = 2, PK_AGGREGATE = 3 };
+
+struct Plan {
+  PlanKind kind = PK_SCAN;
+  Context *ctx = nullptr;
+  std::unique_ptr<Plan> child;
+  std::vector<Batch> batches;       // scan
+  std::vector<ExprPtr> exprs;       // projection
+  ExprPtr pred;                     // selection
+  std::vector<ExprPtr> group_exprs; // aggregate
+  std::vector<AggExpr> aggs;
+  int mode = QE_AGG_MODE_SINGLE;
+  int64_t cap_hint = 0;
+};
+
+static Stream build_stream(std::unique_ptr<Plan> plan) {
+  Context *ctx = plan->ctx;
+  switch (plan->kind) {
+    case PK_SCAN: {
+      auto it = std::make_unique<ScanIter>();
+      it->batches = std::move(plan->batches);
+      Stream s;
+      s.src = std::move(it);
+      return s;
+    }
+    case PK_PROJECTION: {
+      if (!plan->child) fail(QE_ERR_MISSING_INPUT_PHYSICAL_PLAN, "Physical plan `Projection` is missing its input.");
+      Stream s = build_stream(std::move(plan->child));
+      if (s.identity) {
+        // column indices refer to the source directly; a wrong index surfaces at evaluation time
+        s.outputs = plan->exprs;
+      } else {
+        std::vector<ExprPtr> o;
+        for (auto &e : plan->exprs) o.push_back(expr_substitute(e, s.outputs));
+        s.outputs = o;
+      }
+      s.identity = false;
+      return s;
+    }
+    case PK_SELECTION: {
+      if (!plan->child) fail(QE_ERR_MISSING_INPUT_PHYSICAL_PLAN, "Physical plan `Selection` is missing its input.");
+      Stream s = build_stream(std::move(plan->child));
+      ExprPtr p = s.identity ? plan->pred : expr_substitute(plan->pred, s.outputs);
+      s.pred = s.pred ? make_binary(QE_OP_AND, s.pred, p) : p;
+      return s;
+    }
+    case PK_AGGREGATE: {
+      if (!plan->child) fail(QE_ERR_MISSING_INPUT_PHYSICAL_PLAN, "Physical plan `Aggregate` is missing its input.");
+      auto it = std::make_unique<AggIter>();
+      it->ctx = ctx;
+      it->s = build_stream(std::move(plan->child));
+      it->groups = plan->group_exprs;
+      it->aggs = plan->aggs;
+      it->mode = plan->mode;
+      it->cap_hint = plan->cap_hint;
+      Stream s;
+      s.src = std::move(it);
+      return s;
+    }
+  }
+  fail(QE_ERR_PHYSICAL_PLAN_NOT_SUPPORTED, "Physical plan is not supported.");
+}
+
+static std::string plan_to_string(const Plan *p, int indent) {
+  std::ostringstream o;
+  o << std::string(indent * 2, ' ');
+  switch (p->kind) {
+    case PK_SCAN: o << "Scan: memory, batches=" << p->batches.size(); break;
+    case PK_PROJECTION: {
+      o << "Projection: ";
+      for (size_t i = 0; i < p->exprs.size(); ++i) o << (i ? ", " : "") << expr_to_string(p->exprs[i]);
+      break;
+    }
+    case PK_SELECTION: o << "Selection: " << expr_to_string(p->pred); break;
+    case PK_AGGREGATE: {
+      o << "Aggregate: groupExpr=[";
+      for (size_t i = 0; i < p->group_exprs.size(); ++i) o << (i ? ", " : "") << expr_to_string(p->group_exprs[i]);
+      o << "], aggregateExpr=[";
+      static const char *names[] = {"?", "max", "min", "sum", "count", "avg"};
+      for (size_t i = 0; i < p->aggs.size(); ++i)
+        o << (i ? ", " : "") << names[p->aggs[i].kind] << " " << (p->aggs[i].input ? expr_to_string(p->aggs[i].input) : "*");
+      o << "]";
+      break;
+    }
+  }
+  o << "\n";
+  if (p->child) o << plan_to_string(p->child.get(), indent + 1);
+  return o.str();
+}
+
+}  // namespace qe
+
+// ==================================================================== C ABI
+using namespace qe;
+
+struct qe_context { Context c; };
+struct qe_batch { Batch b; };
+struct qe_expr { ExprPtr e; };
+struct qe_agg_expr { AggExpr a; };
+struct qe_plan { std::unique_ptr<Plan> p; };
+struct qe_iter { std::unique_ptr<Iter> it; Context *ctx; };
+
+static thread_local std::string g_last_error;
+
+template <typename F>
+static qe_status guarded(F &&f) {
+  try {
+    f();
+    return QE_OK;
+  } catch (const Failure &e) {
+    g_last_error = e.msg;
+    return e.code;
+  } catch (const std::bad_alloc &) {
+    g_last_error = "out of host memory";
+    return QE_ERR_OUT_OF_MEMORY;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return QE_ERR_INTERNAL;
+  } catch (...) {
+    g_last_error = "unknown failure";
+    return QE_ERR_INTERNAL;
+  }
+}
+
+#define QE_REQUIRE(cond, what) \
+  if (!(cond)) fail(QE_ERR_INVALID_ARGUMENT, what)
+
+static qe_status write_string(const std::string &s, char *buf, int64_t buf_len, int64_t *needed) {
+  if (needed) *needed = (int64_t)s.size();
+  if (buf && buf_len > 0) {
+    size_t nb = std::min<size_t>(s.size(), (size_t)buf_len - 1);
+    std::memcpy(buf, s.data(), nb);
+    buf[nb] = 0;
+  }
+  return QE_OK;
+}
+
+extern "C" {
+
+const char *qe_version(void) { return "qe_gpu 0.1 (gfx950)"; }
+const char *qe_last_error_message(void) { return g_last_error.c_str(); }
+
+const char *qe_status_name(qe_status s) {
+  switch (s) {
+    case QE_OK: return "Ok";
+    case QE_END: return "End";
+    case QE_ERR_EXCEEDING_BOUNDS: return "ExceedingBoundsError";
+    case QE_ERR_NO_FIELD_IN_LOGICAL_PLAN: return "NoFieldInLogicalPlan";
+    case QE_ERR_DIFFERENT_SIZES: return "DifferentSizes";
+    case QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED: return "PhysicalExpressionNotSuported";
+    case QE_ERR_PHYSICAL_PLAN_NOT_SUPPORTED: return "PhysicalPlanNotSuported";
+    case QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED: return "PhysicalTypeNotSuported";
+    case QE_ERR_PRIMITIVE_TYPE_NOT_SUPPORTED: return "PrimitiveTypeNotSuported";
+    case QE_ERR_MISSING_CHILDREN: return "MissingChildren";
+    case QE_ERR_MISSING_INPUT_PHYSICAL_PLAN: return "MissingInputPhysicalPlan";
+    case QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE: return "EmptyHashmapForAggregate";
+    case QE_ERR_DOWNCAST: return "DowncastError";
+    case QE_ERR_SCALAR_TO_ARRAY: return "ScalarToArrayError";
+    case QE_ERR_NO_BOOLEAN_ARRAY_FOR_FILTER: return "NoBooleanArrayForFilter";
+    case QE_ERR_IO: return "IoError";
+    case QE_ERR_ARROW: return "ArrowError";
+    case QE_ERR_INVALID_ARGUMENT: return "InvalidArgument";
+    case QE_ERR_DEVICE: return "DeviceError";
+    case QE_ERR_OUT_OF_MEMORY: return "OutOfMemory";
+    case QE_ERR_AGG_CAPACITY: return "AggregateCapacity";
+    case QE_ERR_INTERNAL: return "Internal";
+    default: return "Unknown";
+  }
+}
+
+int32_t qe_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+qe_status qe_context_create(int32_t device, void *stream, qe_context **out) {
+  return guarded([&] {
+    QE_REQUIRE(out, "out is null");
+    *out = nullptr;
+    int n = qe_device_count();
+    if (device < 0 || device >= n)
+      fail(QE_ERR_DEVICE, "no usable GPU: device " + std::to_string(device) + " of " + std::to_string(n) +
+                              " (this backend has no CPU fallback)");
+    QE_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    QE_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      fail(QE_ERR_DEVICE, std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName);
+    auto ctx = std::make_unique<qe_context>();
+    ctx->c.device = device;
+    ctx->c.dev.cus = prop.multiProcessorCount;
+    ctx->c.dev.max_lds = (int)prop.sharedMemPerBlock;
+    if (stream) {
+      ctx->c.stream = (hipStream_t)stream;
+    } else {
+      QE_HIP(hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking));
+      ctx->c.own_stream = true;
+    }
+    *out = ctx.release();
+  });
+}
+
+qe_status qe_context_set_flags(qe_context *ctx, uint32_t flags) {
+  return guarded([&] {
+    QE_REQUIRE(ctx, "ctx is null");
+    ctx->c.flags = flags;
+  });
+}
+
+qe_status qe_context_synchronize(qe_context *ctx) {
+  return guarded([&] {
+    QE_REQUIRE(ctx, "ctx is null");
+    ctx->c.bind();
+    ctx->c.sync();
+  });
+}
+
+void qe_context_free(qe_context *ctx) { delete ctx; }
+
+// ------------------------------------------------------------------ batches
+static size_t values_size(const qe_column &c) {
+  switch (c.type) {
+    case QE_TYPE_BOOLEAN: return (size_t)((c.length + 7) / 8);
+    case QE_TYPE_UTF8: return (size_t)c.values_bytes;
+    default: return (size_t)c.length * type_width(c.type);
+  }
+}
+
+qe_status qe_batch_import(qe_context *ctx, const qe_column *columns, int32_t n_columns, qe_batch **out) {
+  return guarded([&] {
+    QE_REQUIRE(ctx && out && (columns || n_columns == 0) && n_columns >= 0, "bad arguments");
+    *out = nullptr;
+    auto b = std::make_unique<qe_batch>();
+    b->b.ctx = &ctx->c;
+    int64_t rows = n_columns ? columns[0].length : 0;
+    for (int i = 0; i < n_columns; ++i) {
+      const qe_column &c = columns[i];
+      if (c.type < QE_TYPE_INT32 || c.type > QE_TYPE_UTF8)
+        fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "Physical type `" + std::to_string(c.type) + "` is not supported.");
+      QE_REQUIRE(c.length >= 0, "negative length");
+      if (c.length != rows)
+        fail(QE_ERR_DIFFERENT_SIZES, "The expressions `column 0` and `column " + std::to_string(i) + "` have different sizes.");
+      QE_REQUIRE(c.length == 0 || c.values || (c.type == QE_TYPE_UTF8 && c.values_bytes == 0), "values is null");
+      QE_REQUIRE(c.type != QE_TYPE_UTF8 || c.offsets, "utf8 column needs offsets");
+      QE_REQUIRE(c.memory_space == QE_MEM_HOST || c.memory_space == QE_MEM_DEVICE, "bad memory space");
+      Column col;
+      col.type = c.type;
+      col.space = c.memory_space;
+      col.length = c.length;
+      col.null_count = c.validity ? c.null_count : 0;
+      size_t vs = values_size(c);
+      col.values_bytes = (int64_t)vs;
+      col.values = borrowed_buffer(c.values, vs, c.memory_space);
+      if (c.validity) col.validity = borrowed_buffer(c.validity, (size_t)((c.length + 7) / 8), c.memory_space);
+      if (c.offsets) col.offsets = borrowed_buffer(c.offsets, (size_t)(c.length + 1) * 4, c.memory_space);
+      if (c.memory_space == QE_MEM_DEVICE && type_width(c.type) && ((uintptr_t)c.values & 15u) && vs) {
+        // kernels use 16-byte loads: move a misaligned buffer into an aligned one
+        ctx->c.bind();
+        BufferPtr aligned = device_buffer(&ctx->c, vs + 16);
+        QE_HIP(hipMemcpyAsync(aligned->ptr, c.values, vs, hipMemcpyDeviceToDevice, ctx->c.stream));
+        col.values = aligned;
+      }
+      b->b.cols.push_back(col);
+    }
+    b->b.rows = rows;
+    *out = b.release();
+  });
+}
+
+qe_status qe_batch_num_rows(const qe_batch *batch, int64_t *out) {
+  return guarded([&] {
+    QE_REQUIRE(batch && out, "bad arguments");
+    *out = batch->b.rows;
+  });
+}
+
+qe_status qe_batch_num_columns(const qe_batch *batch, int32_t *out) {
+  return guarded([&] {
+    QE_REQUIRE(batch && out, "bad arguments");
+    *out = (int32_t)batch->b.cols.size();
+  });
+}
+
+static int64_t count_nulls(Context *ctx, const Column &c) {
+  if (!c.validity) return 0;
+  if (c.space == QE_MEM_HOST) {
+    const uint8_t *bm = c.validity_ptr();
+    int64_t z = 0;
+    for (int64_t i = 0; i < c.length; ++i) z += !((bm[i >> 3] >> (i & 7)) & 1);
+    return z;
+  }
+  ctx->bind();
+  ensure_counters(ctx);
+  QE_HIP(hipMemsetAsync(ctx->counters + 1, 0, sizeof(unsigned long long), ctx->stream));
+  QE_HIP(launch_count_zero_bits((const uint32_t *)c.validity->ptr, c.length, ctx->counters + 1, ctx->stream));
+  QE_HIP(hipMemcpyAsync(ctx->host_counters + 1, ctx->counters + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  ctx->sync();
+  return (int64_t)ctx->host_counters[1];
+}
+
+qe_status qe_batch_column(const qe_batch *batch, int32_t index, qe_column *out) {
+  return guarded([&] {
+    QE_REQUIRE(batch && out, "bad arguments");
+    if (index < 0 || index >= (int)batch->b.cols.size())
+      fail(QE_ERR_EXCEEDING_BOUNDS, "The index `" + std::to_string(index) + "` is out of bounds.");
+    Column &c = const_cast<Column &>(batch->b.cols[index]);
+    if (c.null_count < 0) {
+      // output bitmaps are produced by whole-word stores / atomics into padded buffers: count on demand
+      bool word_ok = c.space == QE_MEM_HOST || c.validity->owned;
+      if (word_ok) c.null_count = count_nulls(batch->b.ctx, c);
+    }
+    out->type = c.type;
+    out->memory_space = c.space;
+    out->length = c.length;
+    out->null_count = c.null_count;
+    out->validity = c.validity_ptr();
+    out->offsets = c.offsets_ptr();
+    out->values = c.values_ptr();
+    out->values_bytes = c.values_bytes;
+  });
+}
+
+static Column copy_column(Context *ctx, const Column &c, int to_space) {
+  Column o;
+  o.type = c.type;
+  o.space = to_space;
+  o.length = c.length;
+  o.null_count = c.null_count;
+  o.values_bytes = c.values_bytes;
+  hipMemcpyKind kind = (c.space == QE_MEM_HOST && to_space == QE_MEM_DEVICE)   ? hipMemcpyHostToDevice
+                       : (c.space == QE_MEM_DEVICE && to_space == QE_MEM_HOST) ? hipMemcpyDeviceToHost
+                       : (c.space == QE_MEM_DEVICE)                            ? hipMemcpyDeviceToDevice
+                                                                               : hipMemcpyHostToHost;
+  auto mk = [&](size_t bytes, size_t pad) -> BufferPtr {
+    if (to_space == QE_MEM_DEVICE) {
+      BufferPtr b = device_buffer(ctx, bytes + pad);
+      QE_HIP(hipMemsetAsync(b->ptr, 0, bytes + pad, ctx->stream));
+      return b;
+    }
+    return host_buffer(bytes + pad);
+  };
+  size_t vbytes = c.type == QE_TYPE_BOOLEAN ? (size_t)((c.length + 7) / 8) : (size_t)c.values_bytes;
+  size_t vpad = c.type == QE_TYPE_BOOLEAN ? bitmap_bytes(c.length) - vbytes : 16;
+  o.values = mk(vbytes, vpad);
+  if (vbytes) QE_HIP(hipMemcpyAsync(o.values->ptr, c.values->ptr, vbytes, kind, ctx->stream));
+  if (c.validity) {
+    size_t bb = (size_t)((c.length + 7) / 8);
+    o.validity = mk(bb, bitmap_bytes(c.length) - bb);
+    if (bb) QE_HIP(hipMemcpyAsync(o.validity->ptr, c.validity->ptr, bb, kind, ctx->stream));
+  }
+  if (c.offsets) {
+    size_t ob = (size_t)(c.length + 1) * 4;
+    o.offsets = mk(ob, 16);
+    QE_HIP(hipMemcpyAsync(o.offsets->ptr, c.offsets->ptr, ob, kind, ctx->stream));
+  }
+  return o;
+}
+
+static qe_status copy_batch(qe_context *ctx, const qe_batch *batch, qe_batch **out, int space) {
+  return guarded([&] {
+    QE_REQUIRE(ctx && batch && out, "bad arguments");
+    *out = nullptr;
+    ctx->c.bind();
+    auto b = std::make_unique<qe_batch>();
+    b->b.ctx = &ctx->c;
+    b->b.rows = batch->b.rows;
+    for (auto &c : batch->b.cols) b->b.cols.push_back(copy_column(&ctx->c, c, space));
+    ctx->c.sync();
+    *out = b.release();
+  });
+}
+
+qe_status qe_batch_to_device(qe_context *ctx, const qe_batch *batch, qe_batch **out) { return copy_batch(ctx, batch, out, QE_MEM_DEVICE); }
+qe_status qe_batch_to_host(qe_context *ctx, const qe_batch *batch, qe_batch **out) { return copy_batch(ctx, batch, out, QE_MEM_HOST); }
+void qe_batch_free(qe_batch *batch) { delete batch; }
+
+// -------------------------------------------------------------- expressions
+static qe_status new_expr(ExprPtr e, qe_expr **out) {
+  return guarded([&] {
+    QE_REQUIRE(out, "out is null");
+    *out = new qe_expr{std::move(e)};
+  });
+}
+qe_status qe_expr_column(int32_t index, qe_expr **out) { return new_expr(make_column(index), out); }
+qe_status qe_expr_lit_i32(int32_t v, qe_expr **out) { return new_expr(make_lit_i32(v), out); }
+qe_status qe_expr_lit_i64(int64_t v, qe_expr **out) { return new_expr(make_lit_i64(v), out); }
+qe_status qe_expr_lit_f64(double v, qe_expr **out) { return new_expr(make_lit_f64(v), out); }
+qe_status qe_expr_lit_bool(int32_t v, qe_expr **out) { return new_expr(make_lit_bool(v != 0), out); }
+qe_status qe_expr_lit_utf8(const char *bytes, int64_t len, qe_expr **out) {
+  return guarded([&] {
+    QE_REQUIRE(out && (bytes || len == 0) && len >= 0, "bad arguments");
+    *out = new qe_expr{make_lit_utf8(std::string(bytes ? bytes : "", (size_t)len))};
+  });
+}
+
+qe_status qe_expr_binary(int32_t op, qe_expr *left, qe_expr *right, qe_expr **out) {
+  return guarded([&] {
+    QE_REQUIRE(left && right && out, "bad arguments");
+    if (op < QE_OP_EQ || op > QE_OP_MOD) {
+      delete left;
+      delete right;
+      fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression `op " + std::to_string(op) + "` is not supported.");
+    }
+    ExprPtr e = make_binary(op, left->e, right->e);
+    delete left;
+    delete right;
+    *out = new qe_expr{e};
+  });
+}
+
+qe_status qe_expr_clone(const qe_expr *expr, qe_expr **out) {
+  return guarded([&] {
+    QE_REQUIRE(expr && out, "bad arguments");
+    *out = new qe_expr{expr->e};  // nodes are immutable: sharing is a deep copy in effect
+  });
+}
+
+qe_status qe_expr_to_string(const qe_expr *expr, char *buf, int64_t buf_len, int64_t *needed) {
+  return guarded([&] {
+    QE_REQUIRE(expr, "expr is null");
+    write_string(expr_to_string(expr->e), buf, buf_len, needed);
+  });
+}
+
+qe_status qe_expr_evaluate(qe_context *ctx, const qe_expr *expr, const qe_batch *batch, qe_value *out) {
+  return guarded([&] {
+    QE_REQUIRE(ctx && expr && batch && out, "bad arguments");
+    std::memset(out, 0, sizeof(*out));
+    Schema schema = schema_of(batch->b);
+    ExprPtr e = expr_normalize(expr->e, ctx->c.flags);
+    int t = expr_type(e, schema);
+    out->type = t;
+    if (e->kind == EK_LITERAL) {
+      // literal expressions evaluate to ColumnarValue::Scalar (physical_expressions.rs:84-86 etc.)
+      out->is_scalar = 1;
+      out->scalar_valid = e->valid ? 1 : 0;
+      out->scalar_i64 = e->ival;
+      out->scalar_f64 = e->fval;
+      if (t == QE_TYPE_UTF8) {
+        char *s = (char *)std::malloc(e->sval.size() + 1);
+        std::memcpy(s, e->sval.data(), e->sval.size());
+        s[e->sval.size()] = 0;
+        out->scalar_utf8 = s;
+        out->scalar_utf8_len = (int64_t)e->sval.size();
+      }
+      return;
+    }
+    Batch r = run_pipeline(&ctx->c, batch->b, {e}, nullptr);
+    out->array = new qe_batch{r};
+  });
+}
+
+void qe_value_release(qe_value *value) {
+  if (!value) return;
+  if (value->scalar_utf8) std::free((void *)value->scalar_utf8);
+  delete value->array;
+  std::memset(value, 0, sizeof(*value));
+}
+
+void qe_expr_free(qe_expr *expr) { delete expr; }
+
+qe_status qe_agg_expr_new(int32_t kind, qe_expr *input, qe_agg_expr **out) {
+  return guarded([&] {
+    QE_REQUIRE(out, "out is null");
+    ExprPtr in = input ? input->e : nullptr;
+    delete input;
+    if (kind < QE_AGG_MAX || kind > QE_AGG_AVG)
+      fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression `aggregate " + std::to_string(kind) + "` is not supported.");
+    if (!in && kind != QE_AGG_COUNT) fail(QE_ERR_INVALID_ARGUMENT, "only COUNT may omit its input");
+    *out = new qe_agg_expr{AggExpr{kind, in}};
+  });
+}
+void qe_agg_expr_free(qe_agg_expr *agg) { delete agg; }
+
+// -------------------------------------------------------------------- plans
+qe_status qe_plan_scan_memory(qe_context *ctx, qe_batch *const *batches, int32_t n_batches, qe_plan **out) {
+  return guarded([&] {
+    QE_REQUIRE(ctx && out && (batches || n_batches == 0) && n_batches >= 0, "bad arguments");
+    auto p = std::make_unique<Plan>();
+    p->kind = PK_SCAN;
+    p->ctx = &ctx->c;
+    for (int i = 0; i < n_batches; ++i) {
+      QE_REQUIRE(batches[i], "batch is null");
+      for (auto &c : batches[i]->b.cols)
+        if (c.space != QE_MEM_DEVICE) fail(QE_ERR_INVALID_ARGUMENT, "scan batches must be device resident (qe_batch_to_device)");
+      p->batches.push_back(batches[i]->b);
+    }
+    *out = new qe_plan{std::move(p)};
+  });
+}
+
+qe_status qe_plan_projection(qe_plan *child, qe_expr *const *exprs, int32_t n_exprs, qe_plan **out) {
+  return guarded([&] {
+    QE_REQUIRE(out && (exprs || n_exprs == 0) && n_exprs >= 0, "bad arguments");
+    auto p = std::make_unique<Plan>();
+    p->kind = PK_PROJECTION;
+    for (int i = 0; i < n_exprs; ++i) {
+      QE_REQUIRE(exprs[i], "expr is null");
+      p->exprs.push_back(exprs[i]->e);
+      delete exprs[i];
+    }
+    if (!child) fail(QE_ERR_MISSING_INPUT_PHYSICAL_PLAN, "Physical plan `Projection` is missing its input.");
+    p->ctx = child->p->ctx;
+    p->child = std::move(child->p);
+    delete child;
+    *out = new qe_plan{std::move(p)};
+  });
+}
+
+qe_status qe_plan_selection(qe_plan *child, qe_expr *predicate, qe_plan **out) {
+  return guarded([&] {
+    QE_REQUIRE(out && predicate, "bad arguments");
+    auto p = std::make_unique<Plan>();
+    p->kind = PK_SELECTION;
+    p->pred = predicate->e;
+    delete predicate;
+    if (!child) fail(QE_ERR_MISSING_INPUT_PHYSICAL_PLAN, "Physical plan `Selection` is missing its input.");
+    p->ctx = child->p->ctx;
+    p->child = std::move(child->p);
+    delete child;
+    *out = new qe_plan{std::move(p)};
+  });
+}
+
+qe_status qe_plan_aggregate(qe_plan *child, qe_expr *const *group_exprs, int32_t n_group_exprs,
+                            qe_agg_expr *const *agg_exprs, int32_t n_agg_exprs, int32_t mode,
+                            int64_t group_capacity_hint, qe_plan **out) {
+  return guarded([&] {
+    QE_REQUIRE(out && n_group_exprs >= 0 && n_agg_exprs >= 0, "bad arguments");
+    QE_REQUIRE(mode >= QE_AGG_MODE_SINGLE && mode <= QE_AGG_MODE_FINAL, "bad aggregate mode");
+    auto p = std::make_unique<Plan>();
+    p->kind = PK_AGGREGATE;
+    p->mode = mode;
+    p->cap_hint = group_capacity_hint;
+    for (int i = 0; i < n_group_exprs; ++i) {
+      QE_REQUIRE(group_exprs[i], "group expr is null");
+      p->group_exprs.push_back(group_exprs[i]->e);
+      delete group_exprs[i];
+    }
+    for (int i = 0; i < n_agg_exprs; ++i) {
+      QE_REQUIRE(agg_exprs[i], "aggregate expr is null");
+      p->aggs.push_back(agg_exprs[i]->a);
+      delete agg_exprs[i];
+    }
+    if (!child) fail(QE_ERR_MISSING_INPUT_PHYSICAL_PLAN, "Physical plan `Aggregate` is missing its input.");
+    p->ctx = child->p->ctx;
+    p->child = std::move(child->p);
+    delete child;
+    *out = new qe_plan{std::move(p)};
+  });
+}
+
+qe_status qe_plan_to_string(const qe_plan *plan, char *buf, int64_t buf_len, int64_t *needed) {
+  return guarded([&] {
+    QE_REQUIRE(plan && plan->p, "plan is null");
+    write_string(plan_to_string(plan->p.get(), 0), buf, buf_len, needed);
+  });
+}
+
+qe_status qe_plan_num_children(const qe_plan *plan, int32_t *out) {
+  return guarded([&] {
+    QE_REQUIRE(plan && plan->p && out, "bad arguments");
+    *out = plan->p->child ? 1 : 0;
+  });
+}
+
+void qe_plan_free(qe_plan *plan) { delete plan; }
+
+qe_status qe_plan_execute(qe_plan *plan, qe_iter **out) {
+  return guarded([&] {
+    QE_REQUIRE(plan && plan->p && out, "bad arguments");
+    Context *ctx = plan->p->ctx;
+    std::unique_ptr<Plan> p = std::move(plan->p);
+    delete plan;
+    auto it = std::make_unique<PipeIter>();
+    it->ctx = ctx;
+    it->s = build_stream(std::move(p));
+    *out = new qe_iter{std::move(it), ctx};
+  });
+}
+
+qe_status qe_iter_next(qe_iter *iter, qe_batch **out) {
+  qe_status end = QE_OK;
+  qe_status st = guarded([&] {
+    QE_REQUIRE(iter && out, "bad arguments");
+    *out = nullptr;
+    Batch b;
+    if (!iter->it->next(b)) {
+      end = QE_END;
+      return;
+    }
+    b.ctx = iter->ctx;
+    *out = new qe_batch{b};
+  });
+  return st != QE_OK ? st : end;
+}
+
+void qe_iter_free(qe_iter *iter) { delete iter; }
+
+// ----------------------------------------------------------------- utilities
+qe_status qe_generate_column(qe_context *ctx, int32_t kind, uint64_t seed, int64_t row0, int64_t n, double lo, double hi,
+                             void *device_out) {
+  return guarded([&] {
+    QE_REQUIRE(ctx && (device_out || n == 0) && n >= 0 && kind >= 0 && kind <= 3, "bad arguments");
+    ctx->c.bind();
+    ctx->c.prof_begin("qe_generate_kernel");
+    QE_HIP(launch_generate(kind, seed, row0, n, lo, hi, device_out, ctx->c.stream));
+    ctx->c.prof_end();
+  });
+}
+
+qe_status qe_context_profile(qe_context *ctx, int32_t enable) {
+  return guarded([&] {
+    QE_REQUIRE(ctx, "ctx is null");
+    ctx->c.profiling = enable != 0;
+  });
+}
+
+qe_status qe_context_profile_read(qe_context *ctx, char *buf, int64_t buf_len, int64_t *needed) {
+  return guarded([&] {
+    QE_REQUIRE(ctx, "ctx is null");
+    Context &c = ctx->c;
+    c.bind();
+    c.sync();
+    std::map<std::string, std::pair<int, double>> agg;
+    for (auto &r : c.launches) {
+      float ms = 0;
+      QE_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
+      auto &a = agg[r.name];
+      a.first += 1;
+      a.second += ms;
+      (void)hipEventDestroy(r.start);
+      (void)hipEventDestroy(r.stop);
+    }
+    c.launches.clear();
+    std::ostringstream o;
+    o << "{";
+    bool first = true;
+    for (auto &kv : agg) {
+      o << (first ? "" : ", ") << "\"" << kv.first << "\": {\"launches\": " << kv.second.first << ", \"ms\": " << kv.second.second << "}";
+      first = false;
+    }
+    o << "}";
+    write_string(o.str(), buf, buf_len, needed);
+  });
+}
+
+}  // extern "C"

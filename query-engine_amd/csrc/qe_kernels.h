@@ -1,0 +1,53 @@
+// Host-callable launchers of the gfx950 kernels (defined in qe_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qe_vm.h"
+
+namespace qe {
+
+struct DeviceInfo {
+  int cus;          // compute units
+  int max_lds;      // bytes of LDS one workgroup may use
+};
+
+// Unfiltered projection: every expression of `args` evaluated for every row.
+hipError_t launch_project(const ProjectArgs &args, const DeviceInfo &dev, hipStream_t stream);
+
+// Stable predicate -> compaction (+ projection).  `args.scratch` must hold
+// filter_scratch_bytes(n_rows) bytes, zeroed by launch_filter_reset before every launch.
+hipError_t launch_filter_reset(FilterScratch *scratch, int64_t n_rows, hipStream_t stream);
+hipError_t launch_filter(const FilterArgs &args, const DeviceInfo &dev, hipStream_t stream);
+size_t filter_scratch_bytes(int64_t n_rows);
+int64_t filter_num_tiles(int64_t n_rows);
+
+// Hash aggregate update over one batch.
+hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStream_t stream);
+// LDS bytes per slot for a given accumulator count, and the slot count chosen.
+uint32_t aggregate_lds_slots(int n_accs, const DeviceInfo &dev);
+
+// Fill a fresh global group table with the empty key / accumulator identities.
+hipError_t launch_table_init(const AggTable &table, const VmAcc *accs, int n_accs, hipStream_t stream);
+// Compact occupied slots into output columns.
+hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream);
+
+// utf8 helpers: gather rows `idx[0..m)` of a utf8 column.
+hipError_t launch_utf8_gather_lengths(const int32_t *offsets, const uint8_t *validity, const int64_t *idx, int64_t m,
+                                      int32_t *out_lengths, uint32_t *out_validity, hipStream_t stream);
+hipError_t launch_exclusive_scan_i32(int32_t *data, int64_t n, int32_t *block_sums, hipStream_t stream);
+size_t scan_scratch_elems(int64_t n);
+hipError_t launch_utf8_gather_bytes(const int32_t *src_offsets, const uint8_t *src_bytes, const int64_t *idx, int64_t m,
+                                    const int32_t *dst_offsets, uint8_t *dst_bytes, hipStream_t stream);
+// Broadcast one utf8 literal to `n` rows (scalar_to_array for Utf8, columnar_value.rs:40-50).
+hipError_t launch_utf8_broadcast(const uint8_t *lit, int32_t len, int64_t n, int32_t *out_offsets, uint8_t *out_bytes,
+                                 hipStream_t stream);
+
+// Number of zero bits among the first n bits of a bitmap (null count).
+hipError_t launch_count_zero_bits(const uint32_t *bitmap, int64_t n, unsigned long long *out, hipStream_t stream);
+
+// Synthetic columns (see qe_generate_column in qe_gpu.h).
+hipError_t launch_generate(int kind, uint64_t seed, int64_t row0, int64_t n, double lo, double hi, void *out,
+                           hipStream_t stream);
+
+}  // namespace qe

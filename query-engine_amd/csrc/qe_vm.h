@@ -1,0 +1,198 @@
+// Encoding shared by the host-side expression compiler and the device kernels.
+//
+// A physical expression tree (physical_expressions.rs:22-24 in the reference)
+// is lowered to postfix code for a small stack machine.  One wavefront
+// evaluates one instruction for 256 rows at a time (4 rows per lane), so an
+// instruction's decode cost is shared by 256 rows and every intermediate value
+// stays in vector registers: no per-node array is materialised (the reference
+// allocates one per node, physical_expressions.rs:243-268).
+#pragma once
+#include <stdint.h>
+
+namespace qe {
+
+constexpr int VM_R = 4;              // rows per lane per wave-step
+constexpr int VM_WAVE_ROWS = 256;    // rows per wave-step (64 lanes x 4)
+constexpr int VM_BLOCK_THREADS = 256;
+constexpr int VM_BLOCK_WAVES = 4;
+constexpr int VM_BLOCK_ROWS = VM_WAVE_ROWS * VM_BLOCK_WAVES;  // 1024
+constexpr int VM_MAX_COLS = 24;
+constexpr int VM_MAX_LITS = 32;
+constexpr int VM_MAX_INSN = 128;
+constexpr int VM_MAX_DEPTH = 4;
+constexpr int VM_MAX_OUTS = 12;
+constexpr int VM_MAX_KEYS = 4;
+constexpr int VM_MAX_ACCS = 8;
+
+// Filter tiles: 4 steps of 1024 rows = 4096 rows per ticket.
+constexpr int FILTER_STEPS = 4;
+constexpr int FILTER_TILE_ROWS = VM_BLOCK_ROWS * FILTER_STEPS;
+
+// Instruction word: op[7:0] | depth[11:8] | arg[31:12].
+// `depth` is the stack depth before the instruction executes; the host
+// computes it, so the kernel addresses stack slots with compile-time indices.
+enum VmOp : uint32_t {
+  OP_END = 0,
+  OP_PUSH_COL32,    // arg = column: int32 values, kept sign-extended in 64 bits
+  OP_PUSH_COL64,    // arg = column: int64 / float64 raw bits
+  OP_PUSH_COLBOOL,  // arg = column: bit-packed boolean -> 0/1
+  OP_PUSH_LIT,      // arg = literal index: raw 64 bits, always valid
+  OP_PUSH_ROWID,    // global row index as int64 (arg unused)
+  OP_SWAP,          // exchange the two top slots
+  // arithmetic (wrapping two's complement for integers; IEEE, no FMA, for f64)
+  OP_ADD_I32, OP_SUB_I32, OP_MUL_I32, OP_DIV_I32, OP_MOD_I32,
+  OP_ADD_I64, OP_SUB_I64, OP_MUL_I64, OP_DIV_I64, OP_MOD_I64,
+  OP_ADD_F64, OP_SUB_F64, OP_MUL_F64, OP_DIV_F64,
+  // comparisons -> 0/1.  The I64 forms also serve int32 (sign-extended) and boolean.
+  OP_EQ_I64, OP_NE_I64, OP_LT_I64, OP_LE_I64, OP_GT_I64, OP_GE_I64,
+  OP_EQ_F64, OP_NE_F64, OP_LT_F64, OP_LE_F64, OP_GT_F64, OP_GE_F64,
+  OP_AND, OP_OR,
+  // utf8 comparisons push their boolean result directly.
+  OP_UTF8_EQ_LIT, OP_UTF8_NE_LIT,  // arg = col | lit<<8 (lits[lit] = device ptr, lits[lit+1] = length)
+  OP_UTF8_EQ_COL, OP_UTF8_NE_COL,  // arg = colA | colB<<8
+  OP_I64_TO_F64,                   // top slot: int64 -> float64 (AVG over integers)
+  OP_COUNT_
+};
+
+inline uint32_t vm_insn(uint32_t op, uint32_t depth, uint32_t arg) { return op | (depth << 8) | (arg << 12); }
+
+// Element types of a stack slot / an output column.
+enum VmType : uint8_t { VT_I32 = 1, VT_I64 = 2, VT_F64 = 3, VT_BOOL = 4, VT_UTF8 = 5 };
+
+struct VmCol {
+  const void *values;
+  const uint8_t *validity;  // nullptr = all valid
+  const int32_t *offsets;   // utf8 only
+  uint64_t reserved;
+};
+
+struct VmProgram {
+  VmCol cols[VM_MAX_COLS];
+  uint64_t lits[VM_MAX_LITS];
+  uint32_t insn[VM_MAX_INSN];
+};
+
+struct VmOut {
+  void *values;        // int32/int64/float64 packed values, or boolean bitmap words
+  uint32_t *validity;  // bitmap words or nullptr (output cannot be null)
+  uint32_t pc;         // first instruction of the expression
+  uint8_t type;        // VmType
+  uint8_t pad[3];
+};
+
+struct ProjectArgs {
+  VmProgram prog;
+  VmOut outs[VM_MAX_OUTS];
+  int32_t n_outs;
+  int32_t pad;
+  int64_t n_rows;
+};
+
+// Layout of the per-launch scratch words used by the filter kernel.
+struct FilterScratch {
+  unsigned long long ticket;     // next tile to hand out
+  unsigned long long total;      // number of selected rows (written by the last tile)
+  unsigned long long error;      // non-zero: a bounded spin ran out
+  unsigned long long pad[5];
+  // followed by unsigned long long status[n_tiles]
+};
+
+struct FilterArgs {
+  VmProgram prog;
+  VmOut outs[VM_MAX_OUTS];
+  int32_t n_outs;
+  uint32_t pred_pc;
+  int64_t n_rows;
+  int64_t n_tiles;
+  FilterScratch *scratch;
+};
+
+// Accumulator operations of the hash aggregate.
+enum AccOp : uint8_t {
+  ACC_SUM_I64 = 1,  // wrapping int64 sum of sign-extended integers
+  ACC_SUM_F64 = 2,  // float64 sum (atomic order: not bit-reproducible)
+  ACC_MIN = 3,      // min / max on an order-preserving unsigned image of the value
+  ACC_MAX = 4,
+  ACC_COUNT = 5     // number of valid inputs
+};
+
+struct VmKey {
+  uint32_t pc;
+  uint8_t type;   // VmType (VT_I32, VT_I64, VT_BOOL)
+  uint8_t shift;  // bit position inside the packed 64-bit key
+  uint8_t bits;   // field width
+  uint8_t pad;
+};
+
+struct VmAcc {
+  uint32_t pc;       // input expression (unused when has_input == 0)
+  uint8_t op;        // AccOp
+  uint8_t in_type;   // VmType of the input
+  uint8_t track_nn;  // keep a count of valid inputs next to the accumulator
+  uint8_t has_input; // 0: COUNT(*) style, every row counts
+};
+
+// Global open-addressing group table (structure of arrays, `stride` slots per
+// array; slot `cap` is reserved for the one key equal to the empty marker).
+struct AggTable {
+  unsigned long long *keys;
+  unsigned long long *rowcnt;
+  unsigned long long *acc;  // acc[a * stride + slot]
+  unsigned long long *nn;   // nn[a * stride + slot]
+  unsigned long long *ctrl; // [0] = groups claimed, [1] = overflow flag
+  uint64_t cap;             // power of two
+  uint64_t stride;          // cap + 1 rounded up to 64
+};
+
+constexpr unsigned long long AGG_EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
+
+struct AggArgs {
+  VmProgram prog;
+  VmKey keys[VM_MAX_KEYS];
+  VmAcc accs[VM_MAX_ACCS];
+  AggTable table;
+  int32_t n_keys;
+  int32_t n_accs;
+  int32_t has_pred;
+  uint32_t pred_pc;
+  int64_t n_rows;
+  uint32_t lds_cap;    // LDS table slots (power of two)
+  uint32_t lds_limit;  // stop claiming LDS slots past this many
+};
+
+// One output column of the finalize pass.
+enum FinKind : uint8_t {
+  FIN_KEY = 1,      // unpack key field -> values (type in `type`)
+  FIN_ACC_I64 = 2,  // raw int64 accumulator (truncated to int32 when type == VT_I32)
+  FIN_ACC_F64 = 3,  // raw float64 accumulator
+  FIN_ACC_ORD = 4,  // inverse of the order-preserving image (min / max)
+  FIN_COUNT = 5,    // the count source itself
+  FIN_AVG = 6       // acc[a] (float64) / count source
+};
+// Where a column's count comes from.
+enum FinCnt : uint8_t { CNT_ROWS = 0, CNT_NN = 1, CNT_ACC = 2 };
+// When a result is null.
+enum FinNull : uint8_t { NULL_NEVER = 0, NULL_IF_COUNT_ZERO = 1, NULL_IF_ACC_ALL_ONES = 2, NULL_IF_ACC_ZERO = 3 };
+
+struct FinOut {
+  void *values;
+  uint32_t *validity;  // nullptr or bitmap words (pre-zeroed)
+  uint8_t kind;        // FinKind
+  uint8_t type;        // VmType of the output
+  int8_t a;            // accumulator index (FIN_KEY: key field index)
+  int8_t b;            // accumulator index of the count source (CNT_NN / CNT_ACC)
+  uint8_t shift;       // FIN_KEY
+  uint8_t bits;        // FIN_KEY
+  uint8_t cnt_src;     // FinCnt
+  uint8_t null_mode;   // FinNull
+};
+
+struct FinalizeArgs {
+  AggTable table;
+  FinOut outs[VM_MAX_KEYS + 2 * VM_MAX_ACCS];
+  int32_t n_outs;
+  int32_t pad;
+  unsigned long long *out_count;  // rows written
+};
+
+}  // namespace qe
