@@ -531,9 +531,9 @@ class SelectionExec(PhysicalPlan):
             yield Chunk([filter_array(a, mask) for a in chunk.arrays])
 
 
-def pack_keys(arrays):
-    """Group key columns -> one uint64 per row (Int32: 32 bits, Int64: 64, Boolean: 1) + validity."""
-    n = len(arrays[0]) if arrays else 0
+def pack_keys(arrays, n):
+    """Group key columns -> one uint64 per row (Int32: 32 bits, Int64: 64, Boolean: 1) + validity.
+    No key column: every row gets key 0 (one global group, physical_plan/mod.rs:310-316)."""
     key = np.zeros(n, np.uint64)
     valid = None
     shift = 0
@@ -622,7 +622,7 @@ class AggregateExec(PhysicalPlan):
         per_agg = [[] for _ in self.agg_exprs]
         for ch in chunks:
             gk, ai = self._inputs(ch)
-            k, kv, _ = pack_keys(gk)
+            k, kv, _ = pack_keys(gk, len(ch))
             key_types = [a.type for a in gk]
             all_keys.append(k)
             all_valid.append(np.ones(len(ch), np.bool_) if kv is None else kv)

@@ -103,6 +103,7 @@ Buffer::~Buffer() {
 BufferPtr device_buffer(Context *ctx, size_t bytes) {
   auto b = std::make_shared<Buffer>();
   b->ctx = ctx;
+  b->ctx_ref = ctx->shared_from_this();
   b->ptr = ctx->alloc(bytes, &b->actual);
   b->bytes = bytes;
   b->space = QE_MEM_DEVICE;

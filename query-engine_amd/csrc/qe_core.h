@@ -23,7 +23,7 @@ struct Failure {
 void hip_check(hipError_t e, const char *what);
 #define QE_HIP(expr) ::qe::hip_check((expr), #expr)
 
-struct Context {
+struct Context : std::enable_shared_from_this<Context> {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -54,6 +54,9 @@ struct Context {
 };
 
 struct Buffer {
+  // Owned device blocks keep their context alive: qe_context_free only drops the caller's
+  // reference, the pool is torn down when the last buffer has gone back to it.
+  std::shared_ptr<Context> ctx_ref;
   Context *ctx = nullptr;
   void *ptr = nullptr;
   size_t bytes = 0;   // usable bytes

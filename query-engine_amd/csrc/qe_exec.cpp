@@ -321,6 +321,16 @@ struct AggSpec {
 };
 
 static int add_acc(AggSpec &spec, uint8_t op, int in_type, bool track_nn, const ExprPtr &input) {
+  // aggregates over the same input share one accumulator (AVG(x) next to SUM(x) / COUNT(x))
+  std::string key = input ? expr_to_string(input) : std::string();
+  for (size_t i = 0; i < spec.accs.size(); ++i) {
+    AccDesc &d = spec.accs[i];
+    if (d.acc.op == op && d.acc.in_type == (uint8_t)in_type && (d.input != nullptr) == (input != nullptr) &&
+        (!input || expr_to_string(d.input) == key)) {
+      if (track_nn) d.acc.track_nn = 1;
+      return (int)i;
+    }
+  }
   if ((int)spec.accs.size() >= VM_MAX_ACCS)
     fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many aggregate accumulators for one kernel.");
   AccDesc d;
@@ -702,7 +712,7 @@ static std::string plan_to_string(const Plan *p, int indent) {
 // ==================================================================== C ABI
 using namespace qe;
 
-struct qe_context { Context c; };
+struct qe_context { std::shared_ptr<Context> sp; Context &c; explicit qe_context(std::shared_ptr<Context> p) : sp(std::move(p)), c(*sp) {} };
 struct qe_batch { Batch b; };
 struct qe_expr { ExprPtr e; };
 struct qe_agg_expr { AggExpr a; };
@@ -799,7 +809,7 @@ qe_status qe_context_create(int32_t device, void *stream, qe_context **out) {
     QE_HIP(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
       fail(QE_ERR_DEVICE, std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName);
-    auto ctx = std::make_unique<qe_context>();
+    auto ctx = std::make_unique<qe_context>(std::make_shared<Context>());
     ctx->c.device = device;
     ctx->c.dev.cus = prop.multiProcessorCount;
     ctx->c.dev.max_lds = (int)prop.sharedMemPerBlock;

@@ -920,13 +920,14 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS) void qe_aggregate_kernel(const Ag
 }
 
 // ------------------------------------------------------ table init/finalize
-__global__ void qe_table_init_kernel(AggTable T, uint64_t packed_ops, int n_accs) {
+__global__ void qe_table_init_kernel(AggTable T, uint64_t packed_lo, uint64_t packed_hi, int n_accs) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < T.stride;
        i += (uint64_t)gridDim.x * blockDim.x) {
     T.keys[i] = AGG_EMPTY_KEY;
     T.rowcnt[i] = 0;
     for (int a = 0; a < n_accs; ++a) {
-      T.acc[(uint64_t)a * T.stride + i] = acc_identity((uint32_t)(packed_ops >> (8 * a)) & 0xffu);
+      uint64_t packed = a < 8 ? packed_lo : packed_hi;
+      T.acc[(uint64_t)a * T.stride + i] = acc_identity((uint32_t)(packed >> (8 * (a & 7))) & 0xffu);
       T.nn[(uint64_t)a * T.stride + i] = 0;
     }
   }
@@ -1181,10 +1182,11 @@ hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStrea
 }
 
 hipError_t launch_table_init(const AggTable &table, const VmAcc *accs, int n_accs, hipStream_t stream) {
-  uint64_t packed = 0;
-  for (int i = 0; i < n_accs && i < VM_MAX_ACCS; ++i) packed |= (uint64_t)accs[i].op << (8 * i);
+  static_assert(VM_MAX_ACCS <= 16, "two packed words hold 16 accumulator ops");
+  uint64_t packed[2] = {0, 0};
+  for (int i = 0; i < n_accs && i < VM_MAX_ACCS; ++i) packed[i >> 3] |= (uint64_t)accs[i].op << (8 * (i & 7));
   int grid = grid_for((int64_t)table.stride, 256, 4096);
-  hipLaunchKernelGGL(qe_table_init_kernel, dim3(grid), dim3(256), 0, stream, table, packed, n_accs);
+  hipLaunchKernelGGL(qe_table_init_kernel, dim3(grid), dim3(256), 0, stream, table, packed[0], packed[1], n_accs);
   return hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ constexpr int VM_MAX_INSN = 128;
 constexpr int VM_MAX_DEPTH = 4;
 constexpr int VM_MAX_OUTS = 12;
 constexpr int VM_MAX_KEYS = 4;
-constexpr int VM_MAX_ACCS = 8;
+constexpr int VM_MAX_ACCS = 16;
 
 // Filter tiles: 4 steps of 1024 rows = 4096 rows per ticket.
 constexpr int FILTER_STEPS = 4;

@@ -1,0 +1,371 @@
+"""Parity of the HIP backend (through the C ABI) with the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for integers, booleans, row order / row indices and float64 element-wise results
+(no FMA contraction); float64 SUM / AVG within 1e-12 of the oracle relative to the sum of
+absolute values of the group (reduction order differs).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from util import USERDATA_COLUMNS, assert_batch_equal, assert_column_equal, gpu_batch, load_userdata, sort_by_first_columns
+
+pytestmark = pytest.mark.gpu
+
+COL = {n: i for i, n in enumerate(USERDATA_COLUMNS)}
+_LIT = {"i32": "LiteralIntegerExpression", "i64": "LiteralInt64Expression", "f64": "LiteralFloatExpression",
+        "bool": "LiteralBoolExpression", "str": "LiteralStringExpression"}
+_BIN = {"eq": "EqExpression", "neq": "NeqExpression", "gt": "GtExpression", "gteq": "GtEqExpression", "lt": "LtExpression",
+        "lteq": "LtEqExpression", "and": "AndExpression", "or": "OrExpression", "add": "AddExpression",
+        "sub": "SubExpression", "mul": "MulExpression", "div": "DivExpression", "mod": "ModExpression"}
+_AGG = {"max": "MaxExpression", "min": "MinExpression", "sum": "SumExpression", "count": "CountExpression",
+        "avg": "AvgExpression"}
+
+
+def mk(mod, spec):
+    """Builds the same expression tree in the oracle module or in the product module."""
+    kind = spec[0]
+    if kind == "col":
+        return mod.ColumnExpression(spec[1])
+    if kind in _LIT:
+        return getattr(mod, _LIT[kind])(spec[1])
+    if kind in _AGG:
+        return getattr(mod, _AGG[kind])(mk(mod, spec[1]) if spec[1] is not None else None)
+    return getattr(mod, _BIN[kind])(mk(mod, spec[1]), mk(mod, spec[2]))
+
+
+def C(i):
+    return ("col", i)
+
+
+def rng(seed=7):
+    return np.random.default_rng(seed)
+
+
+def make_columns(n, seed=7, nulls=True):
+    """0: i32, 1: i32, 2: i64, 3: i64, 4: f64, 5: f64, 6: bool, 7: bool (some with nulls)."""
+    r = rng(seed)
+    i32a = r.integers(-2 ** 31, 2 ** 31, n, dtype=np.int64).astype(np.int32)
+    i32b = r.integers(-50, 50, n).astype(np.int32)
+    i64a = r.integers(-2 ** 63, 2 ** 63 - 1, n, dtype=np.int64)
+    i64b = r.integers(-50, 50, n).astype(np.int64)
+    f64a = r.uniform(-1, 1, n)
+    f64b = r.uniform(0, 1, n)
+    ba = r.random(n) > 0.5
+    bb = r.random(n) > 0.3
+    if n > 8:
+        i32a[3], i32b[3] = -2 ** 31, -1
+        i64a[4], i64b[4] = -2 ** 63, -1
+        f64a[5] = np.nan
+        f64b[6] = 0.0
+        f64a[7] = -0.0
+    v = (lambda p: (r.random(n) > p)) if nulls else (lambda p: None)
+    return [orc.Array(orc.INT32, i32a, v(0.1)), orc.Array(orc.INT32, i32b), orc.Array(orc.INT64, i64a), orc.Array(orc.INT64, i64b, v(0.2)),
+            orc.Array(orc.FLOAT64, f64a, v(0.15)), orc.Array(orc.FLOAT64, f64b), orc.Array(orc.BOOLEAN, ba, v(0.1)), orc.Array(orc.BOOLEAN, bb)]
+
+
+SIZES = [1, 2, 63, 255, 256, 257, 1023, 1025, 5000]
+
+EXPRS = [
+    ("add", C(0), C(1)), ("sub", C(0), C(1)), ("mul", C(0), C(1)), ("div", C(0), C(1)), ("mod", C(0), C(1)),
+    ("add", C(2), C(3)), ("sub", C(2), C(3)), ("mul", C(2), C(3)), ("div", C(2), C(3)), ("mod", C(2), C(3)),
+    ("add", C(4), C(5)), ("sub", C(4), C(5)), ("mul", C(4), C(5)), ("div", C(4), C(5)),
+    ("add", C(4), ("mul", C(5), C(5))),                       # a + b*c: two roundings
+    ("add", C(1), ("i32", 7)), ("sub", ("i32", 7), C(1)),     # scalar arms incl. the operand swap
+    ("div", ("i64", 100), C(3)), ("mod", C(3), ("i64", 7)), ("mul", ("f64", 1.5), C(4)), ("div", ("f64", 2.0), C(5)),
+    ("add", ("mul", ("i32", 3), ("i32", 4)), C(1)),           # folded scalar subtree
+    ("eq", C(0), C(1)), ("neq", C(0), C(1)), ("gt", C(0), C(1)), ("gteq", C(1), C(1)), ("lt", C(2), C(3)), ("lteq", C(3), C(3)),
+    ("eq", C(4), C(4)), ("neq", C(4), C(5)), ("gt", C(4), C(5)), ("lt", C(4), ("f64", 0.0)), ("lteq", ("f64", 0.5), C(5)),
+    ("gt", ("i32", 0), C(1)), ("gteq", C(3), ("i64", -3)),
+    ("eq", C(6), C(7)), ("neq", C(6), ("bool", True)), ("and", C(6), C(7)), ("or", C(6), C(7)),
+    ("and", ("gt", C(4), ("f64", 0.0)), ("lt", C(5), ("f64", 0.5))),
+    ("or", ("eq", C(1), ("i32", 3)), ("and", ("gt", C(3), ("i64", 0)), C(7))),
+    # deep right-leaning tree: needs operand reordering to fit four stack slots
+    ("sub", C(4), ("sub", C(5), ("sub", C(4), ("sub", C(5), ("sub", C(4), ("mul", C(5), C(5))))))),
+    ("lt", C(4), ("div", C(5), ("add", C(4), ("sub", C(5), ("mul", C(4), C(5)))))),
+]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_expressions(qe, ctx, n):
+    cols = make_columns(n)
+    chunk = orc.Chunk(cols)
+    batch = gpu_batch(qe, ctx, cols)
+    for spec in EXPRS:
+        want = mk(orc, spec).evaluate(chunk)
+        got = mk(qe, spec).evaluate(batch)
+        assert not want.is_scalar and not got.is_scalar, spec
+        assert_column_equal(got.array.columns()[0], want.array, what=f"n={n} {spec}")
+
+
+def test_evaluate_contract(qe, ctx):
+    cols = make_columns(300)
+    chunk, batch = orc.Chunk(cols), gpu_batch(qe, ctx, cols)
+    # literals and scalar-only trees evaluate to ColumnarValue::Scalar
+    for spec, val in ((("i32", 5), 5), (("f64", 0.25), 0.25), (("bool", True), True), (("str", "abc"), "abc"),
+                      (("add", ("i32", 2 ** 31 - 1), ("i32", 1)), -2 ** 31), (("mul", ("f64", 1.5), ("f64", 2.0)), 3.0),
+                      (("eq", ("i32", 1), ("f64", 1.0)), False), (("eq", ("str", "a"), ("str", "a")), True),
+                      (("div", ("i32", 1), ("i32", 0)), None)):
+        got = mk(qe, spec).evaluate(batch)
+        want = mk(orc, spec).evaluate(chunk)
+        assert got.is_scalar and want.is_scalar
+        assert got.scalar == val and want.scalar.value == val, spec
+    # column pass-through is zero copy and typed
+    got = qe.ColumnExpression(2).evaluate(batch)
+    assert_column_equal(got.array.columns()[0], cols[2])
+    # errors carry the reference's variant
+    for spec, name in ((C(99), "PrimitiveTypeNotSuported"), (("add", C(0), C(2)), "PhysicalTypeNotSuported"),
+                       (("add", ("i32", 1), ("f64", 1.0)), "PhysicalTypeNotSuported"), (("and", C(0), C(1)), "PhysicalTypeNotSuported"),
+                       (("mod", C(4), C(5)), "PhysicalTypeNotSuported")):
+        with pytest.raises(qe.QeError) as e:
+            mk(qe, spec).evaluate(batch)
+        assert e.value.name == name, spec
+        with pytest.raises(orc.OracleError) as e2:
+            mk(orc, spec).evaluate(chunk)
+        assert e2.value.name == name, spec
+    assert str(mk(qe, ("add", C(0), ("mul", C(1), ("f64", 0.5))))) == "#0 + #1 * #0.5"
+
+
+def test_scalar_array_swap_flag(qe, ctx):
+    cols = [orc.Array(orc.INT32, np.array([10, 20, 30], np.int32))]
+    batch = gpu_batch(qe, ctx, cols)
+    spec = ("sub", ("i32", 1), C(0))
+    assert mk(qe, spec).evaluate(batch).array.columns()[0].values.tolist() == [9, 19, 29]  # reference arm
+    ctx.set_flags(0)
+    try:
+        assert mk(qe, spec).evaluate(batch).array.columns()[0].values.tolist() == [-9, -19, -29]
+    finally:
+        ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP)
+
+
+def run_both(qe, ctx, arrays_per_batch, build, sort_keys=None, rtol=None, what=""):
+    """build(mod, scan) -> plan.  Runs it on the oracle and the product; compares every batch."""
+    chunks = [orc.Chunk(a) for a in arrays_per_batch]
+    want = list(build(orc, orc.ScanExec(chunks)).execute())
+    batches = [gpu_batch(qe, ctx, a) for a in arrays_per_batch]
+    got = list(build(qe, qe.ScanExec(ctx, batches)).execute())
+    assert len(got) == len(want), what
+    for g, w in zip(got, want):
+        if sort_keys is None:
+            assert_batch_equal(g, w, rtol=rtol, what=what)
+        else:
+            gc = g.columns()
+            assert len(gc) == len(w.arrays) and g.num_rows == len(w), f"{what}: {g.num_rows} groups != {len(w)}"
+            pg, pw = sort_by_first_columns(gc, sort_keys), sort_by_first_columns(w.arrays, sort_keys)
+            for i, (a, b) in enumerate(zip(gc, w.arrays)):
+                a2 = qe.Column(a.type, np.asarray(a.values)[pg], None if a.validity is None else a.validity[pg])
+                b2 = orc.Array(b.type, b.values[pw], None if b.validity is None else b.validity[pw])
+                if b.type == orc.FLOAT64 and rtol is not None and i in rtol:
+                    ga, wa = np.asarray(a2.values), b2.values
+                    vm = np.ones(len(wa), np.bool_) if b2.validity is None else b2.validity
+                    assert np.array_equal(vm, np.ones(len(wa), np.bool_) if a2.validity is None else a2.validity)
+                    err = np.abs(ga[vm] - wa[vm])
+                    assert (err <= rtol[i][vm]).all(), f"{what} column {i}: max err {err.max()} vs {rtol[i][vm][err.argmax()]}"
+                else:
+                    assert_column_equal(a2, b2, what=f"{what} column {i}")
+    return got, want
+
+
+def test_projection_operator(qe, ctx):
+    for n in (1, 300, 4097):
+        cols = make_columns(n, seed=n)
+        exprs = [C(4), ("add", C(4), ("mul", C(5), C(5))), ("i32", 42), ("f64", 2.5), ("bool", True), ("gt", C(4), ("f64", 0.0)),
+                 ("mul", C(0), C(1)), C(6), ("add", C(2), C(3)), ("and", C(6), C(7))]
+        run_both(qe, ctx, [cols], lambda m, scan: m.ProjectionExec([scan], [mk(m, e) for e in exprs]), what=f"projection n={n}")
+    # more expressions than one launch carries
+    cols = make_columns(1000)
+    exprs = [("add", C(4), ("f64", float(i))) for i in range(30)]
+    run_both(qe, ctx, [cols], lambda m, scan: m.ProjectionExec([scan], [mk(m, e) for e in exprs]), what="projection x30")
+    # projection of a projection
+    run_both(qe, ctx, [cols], lambda m, scan: m.ProjectionExec([m.ProjectionExec([scan], [mk(m, ("mul", C(4), C(5))), mk(m, C(1))])],
+                                                               [mk(m, ("add", C(0), C(0))), mk(m, ("add", C(1), ("i32", 1)))]), what="projection^2")
+
+
+def test_reference_tests_on_device(qe, ctx):
+    """The reference's own test bodies (tests/mod.rs:34-188) against the device operators."""
+    arrays, exp = load_userdata()
+    batch = gpu_batch(qe, ctx, arrays)
+    # test_scan
+    out = list(qe.ScanExec(ctx, [batch]).execute())[0].columns()
+    assert (out[2].values[0], out[3].values[0], out[2].values[1], out[3].values[1]) == (b"Amanda", b"Jordan", b"Albert", b"Freeman")
+    # test_projection
+    out = list(qe.ProjectionExec([qe.ScanExec(ctx, [batch])], [qe.ColumnExpression(COL["email"]), qe.ColumnExpression(COL["country"])]).execute())[0].columns()
+    assert (out[0].values[0], out[1].values[0], out[0].values[1], out[1].values[1]) == (b"ajordan0@com.com", b"Indonesia", b"afreeman1@is.gd", b"Canada")
+    # test_filter: gender == "Female", all 13 columns compacted in order
+    pred = ("eq", C(COL["gender"]), ("str", "Female"))
+    got, want = run_both(qe, ctx, [arrays], lambda m, scan: m.SelectionExec([scan], mk(m, pred)), what="test_filter")
+    out = got[0].columns()
+    assert got[0].num_rows == 482 and len(out) == 13
+    assert (out[2].values[0], out[3].values[0], out[2].values[1], out[3].values[1]) == (b"Amanda", b"Jordan", b"Evelyn", b"Morgan")
+    assert out[COL["salary"]].null_count == int((~want[0].arrays[COL["salary"]].validity).sum())
+    run_both(qe, ctx, [arrays], lambda m, scan: m.SelectionExec([scan], mk(m, ("neq", ("str", "Female"), C(COL["gender"])))), what="neq filter")
+    run_both(qe, ctx, [arrays], lambda m, scan: m.SelectionExec([scan], mk(m, ("eq", C(COL["first_name"]), C(COL["last_name"])))), what="utf8 col==col")
+
+
+@pytest.mark.parametrize("n", [1, 255, 4095, 4096, 4097, 3 * 4096 + 5, 100_000])
+@pytest.mark.parametrize("sel", [0.0, 0.01, 0.5, 0.99, 1.0])
+def test_selection(qe, ctx, n, sel):
+    cols = make_columns(n, seed=n + int(sel * 100))
+    cols[5] = orc.Array(orc.FLOAT64, rng(n).uniform(0, 1, n))
+    pred = ("lt", C(5), ("f64", sel)) if sel < 1.0 else ("lteq", C(5), ("f64", 1.0))
+    got, want = run_both(qe, ctx, [cols], lambda m, scan: m.SelectionExec([scan], mk(m, pred)), what=f"selection n={n} sel={sel}")
+    assert got[0].num_rows == (int((cols[5].values < sel).sum()) if sel < 1.0 else n)
+
+
+def test_selection_null_predicate_and_chains(qe, ctx):
+    cols = make_columns(20_000, seed=3)
+    # predicate with nulls: null drops the row
+    run_both(qe, ctx, [cols], lambda m, scan: m.SelectionExec([scan], mk(m, ("gt", C(4), ("f64", 0.0)))), what="null predicate")
+    run_both(qe, ctx, [cols], lambda m, scan: m.SelectionExec([scan], mk(m, C(6))), what="boolean column predicate")
+    run_both(qe, ctx, [cols], lambda m, scan: m.SelectionExec([scan], mk(m, ("bool", True))), what="literal true")
+    run_both(qe, ctx, [cols], lambda m, scan: m.SelectionExec([scan], mk(m, ("bool", False))), what="literal false")
+    # Scan -> Selection -> Projection (north-star shape c > lit, a + b*c) and deeper chains, several batches
+    parts = [make_columns(n, seed=s) for n, s in ((5000, 1), (1, 2), (9000, 3))]
+
+    def chain(m, scan):
+        s1 = m.SelectionExec([scan], mk(m, ("gt", C(5), ("f64", 0.5))))
+        p1 = m.ProjectionExec([s1], [mk(m, ("add", C(4), ("mul", C(5), C(5)))), mk(m, C(1)), mk(m, C(6)), mk(m, C(3))])
+        s2 = m.SelectionExec([p1], mk(m, ("lt", C(1), ("i32", 25))))
+        return m.ProjectionExec([s2], [mk(m, ("mul", C(0), ("f64", 2.0))), mk(m, C(2)), mk(m, ("add", C(3), ("i64", 1)))])
+    run_both(qe, ctx, parts, chain, what="selection/projection chain")
+    with pytest.raises(qe.QeError) as e:
+        list(qe.SelectionExec([qe.ScanExec(ctx, [gpu_batch(qe, ctx, cols)])], qe.ColumnExpression(0)).execute())
+    assert e.value.name == "NoBooleanArrayForFilter"
+
+
+def agg_tolerances(qe, chunks, group_specs, agg_specs, want):
+    """Absolute tolerance per output row for float64 SUM / AVG columns: 1e-12 x sum |v| of the group
+    (divided by the count for AVG); None for columns compared bit for bit."""
+    tol = {}
+    ng = len(group_specs)
+    for j, a in enumerate(agg_specs):
+        if a[0] not in ("sum", "avg") or a[1] is None:
+            continue
+        vals = [mk(orc, a[1]).evaluate(ch).to_array(len(ch)) for ch in chunks]
+        if vals[0].type != orc.FLOAT64 and a[0] == "sum":
+            continue
+        absed = [orc.Array(orc.FLOAT64, np.abs(v.values.astype(np.float64)), v.validity) for v in vals]
+        keyed = [orc.Chunk([mk(orc, g).evaluate(ch).to_array(len(ch)) for g in group_specs] + [absed[i]]) for i, ch in enumerate(chunks)]
+        plan = orc.AggregateExec([orc.ScanExec(keyed)], [orc.ColumnExpression(i) for i in range(ng)],
+                                 [orc.SumExpression(orc.ColumnExpression(ng)), orc.CountExpression(orc.ColumnExpression(ng))])
+        ref = list(plan.execute())[0]
+        assert all(np.array_equal(ref.arrays[k].values, want.arrays[k].values) for k in range(ng))
+        s = np.where(ref.arrays[ng].validity if ref.arrays[ng].validity is not None else True, ref.arrays[ng].values, 0.0)
+        t = 1e-12 * s
+        if a[0] == "avg":
+            t = t / np.maximum(ref.arrays[ng + 1].values, 1)
+        tol[ng + j] = t
+    return tol
+
+
+def run_agg(qe, ctx, arrays_per_batch, group_specs, agg_specs, hint=0, pred=None, what=""):
+    chunks = [orc.Chunk(a) for a in arrays_per_batch]
+
+    def build(m, scan):
+        src = scan if pred is None else m.SelectionExec([scan], mk(m, pred))
+        if m is orc:
+            return m.AggregateExec([src], [mk(m, g) for g in group_specs], [mk(m, a) for a in agg_specs])
+        return m.AggregateExec([src], [mk(m, g) for g in group_specs], [mk(m, a) for a in agg_specs], group_capacity_hint=hint)
+    want = list(build(orc, orc.ScanExec(chunks)).execute())[0]
+    fchunks = chunks if pred is None else list(orc.SelectionExec([orc.ScanExec(chunks)], mk(orc, pred)).execute())
+    tol = agg_tolerances(qe, fchunks, group_specs, agg_specs, want)
+    # tolerances are in the oracle's first-seen order: re-express them sorted like run_both sorts
+    pw = sort_by_first_columns(want.arrays, len(group_specs))
+    tol_sorted = {k: v[pw] for k, v in tol.items()}
+    return run_both(qe, ctx, arrays_per_batch, build, sort_keys=len(group_specs), rtol=tol_sorted or None, what=what)
+
+
+ALL_AGGS_F64 = [("max", C(2)), ("min", C(2)), ("sum", C(2)), ("count", C(2)), ("count", None), ("avg", C(2))]
+
+
+def agg_columns(n, n_keys, seed, key_dtype=np.int64, nulls=True, zipf=False):
+    r = rng(seed)
+    if zipf:
+        k = (r.zipf(1.3, n) % n_keys).astype(key_dtype)
+    else:
+        k = r.integers(0, n_keys, n).astype(key_dtype)
+    k2 = r.integers(-3, 3, n).astype(np.int32)
+    v = r.uniform(-100, 100, n)
+    iv = r.integers(-2 ** 62, 2 ** 62, n, dtype=np.int64)
+    i32v = r.integers(-2 ** 31, 2 ** 31, n, dtype=np.int64).astype(np.int32)
+    f = r.uniform(0, 1, n)
+    t = orc.INT64 if key_dtype == np.int64 else orc.INT32
+    return [orc.Array(t, k, (r.random(n) > 0.05) if nulls else None), orc.Array(orc.INT32, k2),
+            orc.Array(orc.FLOAT64, v, (r.random(n) > 0.1) if nulls else None), orc.Array(orc.INT64, iv, (r.random(n) > 0.1) if nulls else None),
+            orc.Array(orc.INT32, i32v), orc.Array(orc.FLOAT64, f)]
+
+
+@pytest.mark.parametrize("n,n_keys", [(1, 1), (1000, 1), (5000, 10), (70_000, 10), (70_000, 3000), (200_000, 50_000)])
+def test_aggregate_cardinalities(qe, ctx, n, n_keys):
+    cols = agg_columns(n, n_keys, seed=n + n_keys)
+    run_agg(qe, ctx, [cols], [C(0)], ALL_AGGS_F64, what=f"agg n={n} keys={n_keys}")
+
+
+def test_aggregate_types_and_keys(qe, ctx):
+    cols = agg_columns(30_000, 40, seed=11, key_dtype=np.int32)
+    ints = [("max", C(3)), ("min", C(3)), ("sum", C(3)), ("avg", C(3)), ("sum", C(4)), ("max", C(4)), ("min", C(4)), ("count", C(3))]
+    run_agg(qe, ctx, [cols], [C(0)], ints, what="int aggregates, int32 key")
+    run_agg(qe, ctx, [cols], [C(0), C(1)], ALL_AGGS_F64, what="two int32 keys")
+    run_agg(qe, ctx, [cols], [], ALL_AGGS_F64, what="no group expression: one global group")
+    run_agg(qe, ctx, [cols], [("gt", C(5), ("f64", 0.5)), C(1)], [("sum", C(2)), ("count", None)], what="boolean + int32 key")
+    run_agg(qe, ctx, [cols], [("mod", C(1), ("i32", 2))], [("sum", ("add", C(2), ("mul", C(5), C(5)))), ("max", ("mul", C(4), C(1)))],
+            what="computed key and inputs")
+    # special key values incl. the table's empty marker, and NaN / signed zero in min/max
+    k = np.array([-1, -1, 0, 2 ** 63 - 1, -2 ** 63, -1, 0], dtype=np.int64)
+    v = np.array([1.0, np.nan, -0.0, 5.0, 6.0, 3.0, 0.0])
+    run_agg(qe, ctx, [[orc.Array(orc.INT64, k), orc.Array(orc.INT32, np.zeros(7, np.int32)), orc.Array(orc.FLOAT64, v)]], [C(0)],
+            [("max", C(2)), ("min", C(2)), ("count", None)], what="special keys")
+    allnan = [orc.Array(orc.INT64, np.zeros(4, np.int64)), orc.Array(orc.INT32, np.zeros(4, np.int32)), orc.Array(orc.FLOAT64, np.full(4, np.nan))]
+    got, _ = run_both(qe, ctx, [allnan], lambda m, scan: m.AggregateExec([scan], [mk(m, C(0))], [mk(m, ("count", None))]), sort_keys=1)
+    out = list(qe.AggregateExec([qe.ScanExec(ctx, [gpu_batch(qe, ctx, allnan)])], [qe.ColumnExpression(0)], [qe.MaxExpression(qe.ColumnExpression(2))]).execute())[0].columns()
+    assert out[1].validity is not None and not out[1].validity[0]  # max over only-NaN input is null
+
+
+def test_aggregate_batches_filter_growth_and_errors(qe, ctx):
+    parts = [agg_columns(n, 500, seed=s, zipf=True) for n, s in ((40_000, 1), (1, 2), (25_000, 3), (4096, 4))]
+    run_agg(qe, ctx, parts, [C(0)], ALL_AGGS_F64, what="four batches, skewed keys")
+    run_agg(qe, ctx, parts, [C(0)], ALL_AGGS_F64, pred=("gt", C(5), ("f64", 0.5)), what="filter fused into the aggregate")
+    run_agg(qe, ctx, parts, [C(0)], [("sum", ("add", C(2), ("mul", C(5), C(5)))), ("count", None)], pred=("gt", C(5), ("f64", 0.5)),
+            what="filter -> project -> group by sum (north-star shape)")
+    big = [agg_columns(120_000, 100_000, seed=9, nulls=False)]
+    run_agg(qe, ctx, big, [C(0)], [("sum", C(2)), ("min", C(2)), ("max", C(2)), ("avg", C(2))], hint=64, what="table growth from a tiny hint")
+    empty = [agg_columns(0, 1, seed=1)]
+    with pytest.raises(qe.QeError) as e:
+        list(qe.AggregateExec([qe.ScanExec(ctx, [])], [qe.ColumnExpression(0)], [qe.MaxExpression(qe.ColumnExpression(2))]).execute())
+    assert e.value.name == "EmptyHashmapForAggregate"
+    with pytest.raises(qe.QeError) as e:
+        list(qe.AggregateExec([qe.ScanExec(ctx, [gpu_batch(qe, ctx, empty[0])])], [qe.ColumnExpression(0)], [qe.MaxExpression(qe.ColumnExpression(2))]).execute())
+    assert e.value.name == "EmptyHashmapForAggregate"
+    with pytest.raises(qe.QeError) as e:
+        list(qe.AggregateExec([qe.ScanExec(ctx, [gpu_batch(qe, ctx, parts[0])])], [qe.ColumnExpression(5)], [qe.MaxExpression(qe.ColumnExpression(2))]).execute())
+    assert e.value.name == "PhysicalTypeNotSuported"  # float keys cannot be hashed (physical_plan/mod.rs:317)
+
+
+def test_partial_final_aggregate(qe, ctx):
+    """Two shards aggregated in PARTIAL mode and merged in FINAL mode equal the single aggregate."""
+    cols = agg_columns(60_000, 700, seed=21)
+    half = 31_111
+    shards = [[orc.Array(a.type, a.values[s], None if a.validity is None else a.validity[s]) for a in cols] for s in (slice(0, half), slice(half, None))]
+    groups = [C(0)]
+    aggs = [("max", C(2)), ("min", C(3)), ("sum", C(2)), ("sum", C(4)), ("count", C(2)), ("count", None), ("avg", C(2)), ("avg", C(3))]
+    partials = []
+    for sh in shards:
+        plan = qe.AggregateExec([qe.ScanExec(ctx, [gpu_batch(qe, ctx, sh)])], [mk(qe, g) for g in groups], [mk(qe, a) for a in aggs], mode=qe.AGG_MODE_PARTIAL)
+        partials += list(plan.execute())
+    final = qe.final_plan(qe.ScanExec(ctx, partials), len(groups), [mk(qe, a) for a in aggs])
+    got = list(final.execute())[0]
+    want = list(orc.AggregateExec([orc.ScanExec([orc.Chunk(cols)])], [mk(orc, g) for g in groups], [mk(orc, a) for a in aggs]).execute())[0]
+    tol = agg_tolerances(qe, [orc.Chunk(cols)], groups, aggs, want)
+    gc = got.columns()
+    pg, pw = sort_by_first_columns(gc, 1), sort_by_first_columns(want.arrays, 1)
+    assert got.num_rows == len(want)
+    for i, (a, b) in enumerate(zip(gc, want.arrays)):
+        av = np.asarray(a.values)[pg]
+        bv = b.values[pw]
+        vm = np.ones(len(bv), np.bool_) if b.validity is None else b.validity[pw]
+        am = np.ones(len(bv), np.bool_) if a.validity is None else a.validity[pg]
+        assert np.array_equal(vm, am), i
+        if i in tol:
+            assert (np.abs(av[vm] - bv[vm]) <= tol[i][pw][vm]).all(), i
+        else:
+            assert np.array_equal(av[vm], bv[vm]), i
