@@ -503,13 +503,30 @@ void Compiler::emit(const ExprPtr &e, int depth) {
   switch (e->kind) {
     case EK_COLUMN: {
       int t = expr_type(e, schema);
+      if (t == QE_TYPE_UTF8) fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "Physical type `Utf8` is not supported in a computed expression.");
       int slot = col_slot(e->index);
+      uint32_t kind = t == QE_TYPE_INT32 ? CK_32 : t == QE_TYPE_BOOLEAN ? CK_BOOL : CK_64;
+      auto it = cachemap.find(e->index);
+      int cs = -1;
+      if (it != cachemap.end()) {
+        cs = it->second;
+      } else if ((int)prog.cache_n < VM_NCACHE) {
+        cs = (int)prog.cache_n++;
+        prog.cache_col[cs] = (uint8_t)slot;
+        prog.cache_kind[cs] = (uint8_t)kind;
+        cachemap[e->index] = cs;
+      }
+      if (cs >= 0) {
+        last_cache_mask |= 1u << cs;
+        all_cache_mask |= 1u << cs;
+        push_insn(kind == CK_32 ? OP_PUSH_CACHED32 : kind == CK_BOOL ? OP_PUSH_CACHEDBOOL : OP_PUSH_CACHED64, depth, (uint32_t)cs);
+        return;
+      }
       switch (t) {
         case QE_TYPE_INT32: push_insn(OP_PUSH_COL32, depth, slot); break;
         case QE_TYPE_INT64:
         case QE_TYPE_FLOAT64: push_insn(OP_PUSH_COL64, depth, slot); break;
-        case QE_TYPE_BOOLEAN: push_insn(OP_PUSH_COLBOOL, depth, slot); break;
-        default: fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "Physical type `Utf8` is not supported in a computed expression.");
+        default: push_insn(OP_PUSH_COLBOOL, depth, slot); break;
       }
       return;
     }
@@ -579,6 +596,7 @@ void Compiler::emit(const ExprPtr &e, int depth) {
 
 uint32_t Compiler::add(const ExprPtr &e) {
   uint32_t start = (uint32_t)n_insn;
+  last_cache_mask = 0;
   emit(e, 0);
   push_insn(OP_END, 0, 0);
   return start;

@@ -153,6 +153,9 @@ struct Compiler {
   VmProgram prog{};
   int n_insn = 0, n_lits = 0, n_cols = 0;
   std::map<int, int> colmap;           // batch column -> program column
+  std::map<int, int> cachemap;         // batch column -> cache slot
+  uint32_t last_cache_mask = 0;        // cache slots read by the expression added last
+  uint32_t all_cache_mask = 0;         // ... by every expression added so far
   std::vector<BufferPtr> keepalive;    // device copies of utf8 literals
   Compiler(Context *c, const Batch *b);
   // Space check before adding an expression: worst-case instruction / literal / column needs.

@@ -242,6 +242,7 @@ static Batch run_pipeline(Context *ctx, const Batch &in, const std::vector<ExprP
     Compiler comp(ctx, &in);
     FilterArgs args{};
     args.pred_pc = comp.add(pred);
+    args.pred_cache_mask = comp.last_cache_mask;
     int cnt = 0;
     if (first && need_rowid) {
       rowid = make_fixed_column(ctx, QE_TYPE_INT64, n, false, false);
@@ -257,6 +258,7 @@ static Batch run_pipeline(Context *ctx, const Batch &in, const std::vector<ExprP
       Column c = make_fixed_column(ctx, types[i], n, nullable, false);
       VmOut &o = args.outs[cnt];
       o.pc = comp.add(outs[i]);
+      args.out_cache_mask |= comp.last_cache_mask;
       o.type = vm_type_of(types[i]);
       o.values = c.values->ptr;
       o.validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
@@ -541,21 +543,25 @@ struct AggIter : Iter {
         Compiler comp(ctx, &in);
         AggArgs args{};
         ExprPtr pred = s.pred ? expr_normalize(s.pred, ctx->flags) : nullptr;
+        int nt = 0;
         if (pred) {
           if (expr_type(pred, schema) != QE_TYPE_BOOLEAN)
             fail(QE_ERR_NO_BOOLEAN_ARRAY_FOR_FILTER, "Expr doesn't evaluate to a boolean array, which is needed to filter.");
-          args.has_pred = 1;
-          args.pred_pc = comp.add(pred);
+          args.tasks[nt++] = VmTask{comp.add(pred), ROLE_PRED, 0, 1, 0};
         }
         for (size_t i = 0; i < bspec.keys.size(); ++i) {
           args.keys[i] = bspec.keys[i];
           args.keys[i].pc = comp.add(bspec.key_exprs[i]);
+          args.tasks[nt++] = VmTask{args.keys[i].pc, ROLE_KEY, (uint8_t)i, 1, 0};
         }
+        args.tasks[nt++] = VmTask{0, ROLE_LOOKUP, 0, 0, 0};
         for (size_t i = 0; i < bspec.accs.size(); ++i) {
           args.accs[i] = bspec.accs[i].acc;
           args.accs[i].track_nn = spec.accs[i].acc.track_nn;
           if (bspec.accs[i].input) args.accs[i].pc = comp.add(bspec.accs[i].input);
+          args.tasks[nt++] = VmTask{args.accs[i].pc, ROLE_ACC, (uint8_t)i, (uint8_t)(bspec.accs[i].input ? 1 : 0), 0};
         }
+        args.n_tasks = nt;
         args.prog = comp.prog;
         args.table = table;
         args.n_keys = (int)bspec.keys.size();

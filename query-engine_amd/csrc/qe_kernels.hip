@@ -9,13 +9,21 @@
 //   * qe_finalize_kernel  — group table -> output batch (physical_plan/mod.rs:375-488)
 // All of them are HBM-bandwidth bound byte/integer/f64 streaming work: wide coalesced loads,
 // wave64 ballot/popcount ranking, LDS scans and LDS atomics; there is no dense contraction here.
+//
+// Code size is a first-order cost for the interpreter kernels: the instruction cache holds
+// 64 KiB and a wave that jumps around a larger body stalls on instruction fetch.  Hence every
+// kernel instantiates the interpreter ONCE, rare operations share one out-of-line-style copy
+// that works on temporaries, and per-row work that is more than a few instructions long runs in
+// a rolled loop that rotates the four row registers instead of being unrolled four times.
 #include "qe_kernels.h"
 
 namespace qe {
 
 // ------------------------------------------------------------------ helpers
 // Column value buffers are 16-byte aligned (the host re-aligns imported buffers that are not),
-// so a lane's row pair is one global_load_dwordx4 / global_store_dwordx4.
+// so a lane's row pair is one global_load_dwordx4 / global_store_dwordx4.  A pair that starts on
+// a valid row never leaves the 16-byte granule of that row, so it cannot cross into an unmapped
+// page even when the second row is past the end of the column.
 struct alignas(16) U64x2 { uint64_t x, y; };
 struct alignas(8) U32x2 { uint32_t x, y; };
 
@@ -49,8 +57,32 @@ __device__ __forceinline__ uint32_t in_range_bits(int64_t row0, uint32_t lane, i
   return a;
 }
 
+// Hides a lane-varying value from loop-invariant code motion: without it everything the
+// interpreter might derive from loop-invariant registers (addresses from the lane id, decoded
+// forms of every cached column) is precomputed ahead of the instruction loop and kept live
+// across it, which costs far more registers than the work saved.
+__device__ __forceinline__ uint32_t opaque(uint32_t x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+__device__ __forceinline__ uint64_t opaque64(uint64_t x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 __device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
 __device__ __forceinline__ uint64_t d2u(double d) { return (uint64_t)__double_as_longlong(d); }
+
+__device__ __forceinline__ uint32_t rot4(uint32_t m) { return ((m >> 1) | (m << 3)) & 0xFu; }
+#define QE_ROT4(a)   \
+  {                  \
+    auto t_ = (a)[0]; \
+    (a)[0] = (a)[1]; \
+    (a)[1] = (a)[2]; \
+    (a)[2] = (a)[3]; \
+    (a)[3] = t_;     \
+  }
 
 // Two adjacent bits (rows 2l, 2l+1 of each chunk) out of an LSB-first bitmap.
 __device__ __forceinline__ uint32_t load_bits4(const uint8_t *bm, const RowCtx &c) {
@@ -73,178 +105,193 @@ __device__ __forceinline__ bool utf8_equal(const uint8_t *a, const uint8_t *b, i
   return true;
 }
 
+// ------------------------------------------------------- per-step column cache
+// Raw bits of up to VM_NCACHE columns for the 4 rows of the lane.  Filled by cache_load with
+// every load in flight at once; only ever indexed with compile-time constants.
+struct ColCache {
+  uint64_t v[VM_NCACHE][VM_R];
+  uint32_t valid[VM_NCACHE];  // validity bits (4 per lane), 0xF when the column has no bitmap
+};
+
+__device__ __forceinline__ void cache_load_one(const VmProgram &P, int i, const RowCtx &c, uint64_t (&v)[VM_R],
+                                               uint32_t &valid) {
+  const VmCol &col = P.cols[P.cache_col[i]];
+  const uint32_t kind = P.cache_kind[i];
+  // every path produces the four words in locals and the cache entry is written once, below:
+  // storing from inside the branches makes the compiler merge them into one store with a
+  // computed index, which pushes the whole cache out to scratch memory
+  uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+  const int64_t r0 = c.row0 + 2 * (int64_t)c.lane;
+  const int64_t r1 = r0 + 128;
+  const bool a0 = (c.active & 3u) != 0, a1 = (c.active & 12u) != 0;
+  if (kind == CK_64) {
+    const uint64_t *p = (const uint64_t *)col.values;
+    if (a0) {
+      U64x2 t = *(const U64x2 *)(p + r0);
+      w0 = t.x;
+      w1 = t.y;
+    }
+    if (a1) {
+      U64x2 t = *(const U64x2 *)(p + r1);
+      w2 = t.x;
+      w3 = t.y;
+    }
+  } else if (kind == CK_32) {
+    const uint32_t *p = (const uint32_t *)col.values;  // raw pairs; sign-extended when pushed
+    if (a0) {
+      U32x2 t = *(const U32x2 *)(p + r0);
+      w0 = (uint64_t)t.x | ((uint64_t)t.y << 32);
+    }
+    if (a1) {
+      U32x2 t = *(const U32x2 *)(p + r1);
+      w1 = (uint64_t)t.x | ((uint64_t)t.y << 32);
+    }
+  } else {
+    w0 = load_bits4((const uint8_t *)col.values, c);
+  }
+  uint32_t vb = 0xFu;
+  if (col.validity) vb = load_bits4(col.validity, c);
+  v[0] = w0;
+  v[1] = w1;
+  v[2] = w2;
+  v[3] = w3;
+  valid = vb;
+}
+
+template <int I>
+__device__ __forceinline__ void cache_load_from(const VmProgram &P, uint32_t mask, const RowCtx &c, ColCache &K) {
+  if constexpr (I < VM_NCACHE) {
+    if ((mask >> I) & 1u) cache_load_one(P, I, c, K.v[I], K.valid[I]);
+    cache_load_from<I + 1>(P, mask, c, K);
+  }
+}
+__device__ __forceinline__ void cache_load(const VmProgram &P, uint32_t mask, const RowCtx &c, ColCache &K) {
+  cache_load_from<0>(P, mask, c, K);
+}
+
 // ------------------------------------------------------------ the VM proper
-__device__ __forceinline__ void vm_push(uint32_t op, uint32_t arg, const VmProgram &P, const RowCtx &c, Slot &s) {
-  switch (op) {
-    case OP_PUSH_COL64: {
-      const VmCol &col = P.cols[arg];
-      const uint64_t *p = (const uint64_t *)col.values;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        uint32_t a2 = (c.active >> (2 * h)) & 3u;
-        int64_t r = c.row0 + h * 128 + 2 * (int64_t)c.lane;
-        uint64_t x = 0, y = 0;
-        if (a2) {
-          if (r + 1 < c.n) {
-            U64x2 t = *(const U64x2 *)(p + r);
-            x = t.x;
-            y = t.y;
-          } else {
-            x = p[r];
-          }
-        }
-        s.v[2 * h] = x;
-        s.v[2 * h + 1] = y;
-      }
-      s.valid = col.validity ? load_bits4(col.validity, c) : 0xFu;
-      break;
-    }
-    case OP_PUSH_COL32: {
-      const VmCol &col = P.cols[arg];
-      const int32_t *p = (const int32_t *)col.values;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        uint32_t a2 = (c.active >> (2 * h)) & 3u;
-        int64_t r = c.row0 + h * 128 + 2 * (int64_t)c.lane;
-        int32_t x = 0, y = 0;
-        if (a2) {
-          if (r + 1 < c.n) {
-            U32x2 t = *(const U32x2 *)(p + r);
-            x = (int32_t)t.x;
-            y = (int32_t)t.y;
-          } else {
-            x = p[r];
-          }
-        }
-        s.v[2 * h] = (uint64_t)(int64_t)x;
-        s.v[2 * h + 1] = (uint64_t)(int64_t)y;
-      }
-      s.valid = col.validity ? load_bits4(col.validity, c) : 0xFu;
-      break;
-    }
-    case OP_PUSH_COLBOOL: {
-      const VmCol &col = P.cols[arg];
-      uint32_t b = load_bits4((const uint8_t *)col.values, c);
-#pragma unroll
-      for (int j = 0; j < VM_R; ++j) s.v[j] = (b >> j) & 1u;
-      s.valid = col.validity ? load_bits4(col.validity, c) : 0xFu;
-      break;
-    }
-    case OP_PUSH_LIT: {
-      uint64_t l = P.lits[arg];
-#pragma unroll
-      for (int j = 0; j < VM_R; ++j) s.v[j] = l;
-      s.valid = 0xFu;
-      break;
-    }
-    case OP_PUSH_ROWID: {
-#pragma unroll
-      for (int j = 0; j < VM_R; ++j) s.v[j] = (uint64_t)(c.row0 + (j >> 1) * 128 + 2 * (int64_t)c.lane + (j & 1));
-      s.valid = 0xFu;
-      break;
-    }
-    case OP_UTF8_EQ_LIT:
-    case OP_UTF8_NE_LIT: {
-      const VmCol &col = P.cols[arg & 0xffu];
-      uint32_t li = (arg >> 8) & 0xffu;
-      const uint8_t *lit = (const uint8_t *)P.lits[li];
-      int32_t llen = (int32_t)P.lits[li + 1];
-      const uint8_t *bytes = (const uint8_t *)col.values;
-      uint32_t want = (op == OP_UTF8_EQ_LIT) ? 1u : 0u;
-#pragma unroll
-      for (int j = 0; j < VM_R; ++j) {
-        uint64_t res = 0;
-        if ((c.active >> j) & 1u) {
-          int64_t r = c.row0 + (j >> 1) * 128 + 2 * (int64_t)c.lane + (j & 1);
-          int32_t o0 = col.offsets[r], o1 = col.offsets[r + 1];
-          bool eq = (o1 - o0 == llen) && utf8_equal(bytes + o0, lit, llen);
-          res = (eq ? 1u : 0u) == want ? 1u : 0u;
-        }
-        s.v[j] = res;
-      }
-      s.valid = col.validity ? load_bits4(col.validity, c) : 0xFu;
-      break;
-    }
-    case OP_UTF8_EQ_COL:
-    case OP_UTF8_NE_COL: {
-      const VmCol &ca = P.cols[arg & 0xffu];
-      const VmCol &cb = P.cols[(arg >> 8) & 0xffu];
-      uint32_t want = (op == OP_UTF8_EQ_COL) ? 1u : 0u;
-#pragma unroll
-      for (int j = 0; j < VM_R; ++j) {
-        uint64_t res = 0;
-        if ((c.active >> j) & 1u) {
-          int64_t r = c.row0 + (j >> 1) * 128 + 2 * (int64_t)c.lane + (j & 1);
-          int32_t a0 = ca.offsets[r], a1 = ca.offsets[r + 1];
-          int32_t b0 = cb.offsets[r], b1 = cb.offsets[r + 1];
-          bool eq = (a1 - a0 == b1 - b0) &&
-                    utf8_equal((const uint8_t *)ca.values + a0, (const uint8_t *)cb.values + b0, a1 - a0);
-          res = (eq ? 1u : 0u) == want ? 1u : 0u;
-        }
-        s.v[j] = res;
-      }
-      uint32_t va = ca.validity ? load_bits4(ca.validity, c) : 0xFu;
-      uint32_t vb = cb.validity ? load_bits4(cb.validity, c) : 0xFu;
-      s.valid = va & vb;
-      break;
-    }
-    default:
-      break;
+// The program (instruction words, literals) is wave-uniform data that the interpreter reads at a
+// run-time index.  Reading it from the kernel-argument segment costs one scalar-memory round
+// trip per fetch, in a dependent chain; instead lane i of a few VGPRs holds word i, loaded once
+// per kernel, and a fetch is a v_readlane_b32.
+struct ProgRegs {
+  uint32_t code0, code1;    // insn[lane], insn[64 + lane]
+  uint32_t lit_lo, lit_hi;  // lits[lane & 31]
+};
+static_assert(VM_MAX_INSN == 128 && VM_MAX_LITS <= 64, "ProgRegs layout");
+
+__device__ __forceinline__ ProgRegs prog_regs(const VmProgram &P, uint32_t lane) {
+  ProgRegs R;
+  R.code0 = P.insn[lane];
+  R.code1 = P.insn[64 + lane];
+  uint64_t l = P.lits[lane & (VM_MAX_LITS - 1)];
+  R.lit_lo = (uint32_t)l;
+  R.lit_hi = (uint32_t)(l >> 32);
+  return R;
+}
+__device__ __forceinline__ uint32_t fetch_insn(const ProgRegs &R, uint32_t pc) {
+  return pc < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)R.code0, (int)pc)
+                 : (uint32_t)__builtin_amdgcn_readlane((int)R.code1, (int)(pc - 64));
+}
+__device__ __forceinline__ uint64_t fetch_lit(const ProgRegs &R, uint32_t i) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)R.lit_lo, (int)i);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)R.lit_hi, (int)i);
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// Selecting a stack slot / cache entry by a run-time (wave-uniform) number.  Each case passes
+// its values through `opaque`: otherwise the optimiser folds the cases into one access with a
+// computed index, and an array indexed that way is placed in scratch memory instead of registers.
+__device__ __forceinline__ void slot_copy(Slot &r, const Slot &s) {
+  // element by element: a whole-struct copy is a memcpy to the optimiser and leaves the
+  // slots in scratch memory
+  r.v[0] = opaque64(s.v[0]);
+  r.v[1] = opaque64(s.v[1]);
+  r.v[2] = opaque64(s.v[2]);
+  r.v[3] = opaque64(s.v[3]);
+  r.valid = opaque(s.valid);
+}
+__device__ __forceinline__ void slot_get(const Slot (&S)[VM_MAX_DEPTH], uint32_t i, Slot &out) {
+  switch (i) {
+    case 0: slot_copy(out, S[0]); break;
+    case 1: slot_copy(out, S[1]); break;
+    case 2: slot_copy(out, S[2]); break;
+    default: slot_copy(out, S[3]); break;
+  }
+}
+__device__ __forceinline__ void slot_put(Slot (&S)[VM_MAX_DEPTH], uint32_t i, const Slot &x) {
+  switch (i) {
+    case 0: slot_copy(S[0], x); break;
+    case 1: slot_copy(S[1], x); break;
+    case 2: slot_copy(S[2], x); break;
+    default: slot_copy(S[3], x); break;
   }
 }
 
-#define QE_BIN_EACH(expr)                 \
+__device__ __forceinline__ void cached_raw(const ColCache &K, uint32_t slot, uint64_t (&v)[VM_R], uint32_t &valid) {
+#define QE_TAKE(i)                                                               \
+  {                                                                              \
+    _Pragma("unroll") for (int j = 0; j < VM_R; ++j) v[j] = opaque64(K.v[i][j]); \
+    valid = opaque(K.valid[i]);                                                  \
+  }
+  switch (slot) {
+    case 0: QE_TAKE(0) break;
+    case 1: QE_TAKE(1) break;
+    case 2: QE_TAKE(2) break;
+    case 3: QE_TAKE(3) break;
+    case 4: QE_TAKE(4) break;
+    default: QE_TAKE(5) break;
+  }
+#undef QE_TAKE
+}
+
+// Hot pushes, instantiated per stack depth: a cached column or a literal.
+__device__ __forceinline__ void vm_push_fast(uint32_t op, uint32_t arg, const ProgRegs &R, const ColCache &K, Slot &s) {
+  if (op == OP_PUSH_LIT) {
+    uint64_t l = fetch_lit(R, arg);
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) s.v[j] = l;
+    s.valid = 0xFu;
+    return;
+  }
+  cached_raw(K, arg, s.v, s.valid);
+  if (op == OP_PUSH_CACHED32) {
+    // raw int32 pairs -> sign-extended values.  `opaque`: decoded here, per instruction; left
+    // visible, the decoded form of every cache slot is precomputed ahead of the instruction loop
+    uint32_t w0 = opaque((uint32_t)s.v[0]), w1 = opaque((uint32_t)(s.v[0] >> 32));
+    uint32_t w2 = opaque((uint32_t)s.v[1]), w3 = opaque((uint32_t)(s.v[1] >> 32));
+    s.v[0] = (uint64_t)(int64_t)(int32_t)w0;
+    s.v[1] = (uint64_t)(int64_t)(int32_t)w1;
+    s.v[2] = (uint64_t)(int64_t)(int32_t)w2;
+    s.v[3] = (uint64_t)(int64_t)(int32_t)w3;
+  } else if (op == OP_PUSH_CACHEDBOOL) {
+    uint32_t bits = opaque((uint32_t)s.v[0]);
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) s.v[j] = (bits >> j) & 1u;
+  }
+}
+
+#define QE_BIN_EACH(expr)                            \
   _Pragma("unroll") for (int j = 0; j < VM_R; ++j) { \
-    uint64_t x = a.v[j], y = b.v[j];      \
-    (void)x; (void)y;                     \
-    a.v[j] = (expr);                      \
+    uint64_t x = a.v[j], y = b.v[j];                 \
+    (void)x;                                         \
+    (void)y;                                         \
+    a.v[j] = (expr);                                 \
   }
 
-// a = a OP b for the 4 rows of the lane.  Result validity = AND of the operands
-// (arrow2 binary kernels combine validity bitmaps the same way).
-__device__ __forceinline__ void vm_binary(uint32_t op, Slot &a, const Slot &b) {
-  uint32_t valid = a.valid & b.valid;
+// Hot binaries, instantiated per stack depth: a = a OP b.  Result validity = AND of the
+// operands (arrow2 binary kernels combine validity bitmaps the same way).
+__device__ __forceinline__ void vm_binary_fast(uint32_t op, Slot &a, const Slot &b) {
   switch (op) {
     case OP_ADD_I32: QE_BIN_EACH((uint64_t)(int64_t)(int32_t)((uint32_t)x + (uint32_t)y)); break;
     case OP_SUB_I32: QE_BIN_EACH((uint64_t)(int64_t)(int32_t)((uint32_t)x - (uint32_t)y)); break;
     case OP_MUL_I32: QE_BIN_EACH((uint64_t)(int64_t)(int32_t)((uint32_t)x * (uint32_t)y)); break;
-    case OP_DIV_I32:
-    case OP_MOD_I32: {
-#pragma unroll
-      for (int j = 0; j < VM_R; ++j) {
-        int32_t x = (int32_t)a.v[j], y = (int32_t)b.v[j];
-        int32_t r = 0;
-        if (y == 0 || (x == INT32_MIN && y == -1)) {
-          valid &= ~(1u << j);  // the reference panics here; this backend yields null
-        } else {
-          r = (op == OP_DIV_I32) ? x / y : x % y;
-        }
-        a.v[j] = (uint64_t)(int64_t)r;
-      }
-      break;
-    }
     case OP_ADD_I64: QE_BIN_EACH(x + y); break;
     case OP_SUB_I64: QE_BIN_EACH(x - y); break;
     case OP_MUL_I64: QE_BIN_EACH(x * y); break;
-    case OP_DIV_I64:
-    case OP_MOD_I64: {
-#pragma unroll
-      for (int j = 0; j < VM_R; ++j) {
-        int64_t x = (int64_t)a.v[j], y = (int64_t)b.v[j];
-        int64_t r = 0;
-        if (y == 0 || (x == INT64_MIN && y == -1)) {
-          valid &= ~(1u << j);
-        } else {
-          r = (op == OP_DIV_I64) ? x / y : x % y;
-        }
-        a.v[j] = (uint64_t)r;
-      }
-      break;
-    }
     case OP_ADD_F64: QE_BIN_EACH(d2u(u2d(x) + u2d(y))); break;
     case OP_SUB_F64: QE_BIN_EACH(d2u(u2d(x) - u2d(y))); break;
     case OP_MUL_F64: QE_BIN_EACH(d2u(u2d(x) * u2d(y))); break;
-    case OP_DIV_F64: QE_BIN_EACH(d2u(u2d(x) / u2d(y))); break;
     case OP_EQ_I64: QE_BIN_EACH((uint64_t)(x == y)); break;
     case OP_NE_I64: QE_BIN_EACH((uint64_t)(x != y)); break;
     case OP_LT_I64: QE_BIN_EACH((uint64_t)((int64_t)x < (int64_t)y)); break;
@@ -258,65 +305,204 @@ __device__ __forceinline__ void vm_binary(uint32_t op, Slot &a, const Slot &b) {
     case OP_GT_F64: QE_BIN_EACH((uint64_t)(u2d(x) > u2d(y))); break;
     case OP_GE_F64: QE_BIN_EACH((uint64_t)(u2d(x) >= u2d(y))); break;
     case OP_AND: QE_BIN_EACH(x & y); break;
-    case OP_OR: QE_BIN_EACH(x | y); break;
-    default: break;
+    default: QE_BIN_EACH(x | y); break;  // OP_OR
   }
-  a.valid = valid;
+  a.valid &= b.valid;
 }
 
-__device__ __forceinline__ void vm_swap(Slot &a, Slot &b) {
-#pragma unroll
-  for (int j = 0; j < VM_R; ++j) {
-    uint64_t t = a.v[j];
-    a.v[j] = b.v[j];
-    b.v[j] = t;
-  }
-  uint32_t t = a.valid;
-  a.valid = b.valid;
-  b.valid = t;
+__device__ __forceinline__ bool op_is_fast_push(uint32_t op) { return op >= OP_PUSH_CACHED64 || op == OP_PUSH_LIT; }
+__device__ __forceinline__ bool op_is_fast_binary(uint32_t op) {
+  return (op >= OP_ADD_I32 && op <= OP_MUL_I32) || (op >= OP_ADD_I64 && op <= OP_MUL_I64) ||
+         (op >= OP_ADD_F64 && op <= OP_MUL_F64) || (op >= OP_EQ_I64 && op <= OP_OR);
 }
 
-__device__ __forceinline__ void vm_i64_to_f64(Slot &a) {
+// Everything else: one copy for all stack depths.  Operands are copied into the temporaries
+// a / b, the result goes back through slot_put.  `d` is the stack depth before the instruction.
+__device__ __forceinline__ void vm_slow(uint32_t op, uint32_t d, uint32_t arg, const VmProgram &P, const RowCtx &c0,
+                                        const ColCache &K, Slot (&S)[VM_MAX_DEPTH]) {
+  RowCtx c;
+  c.row0 = c0.row0;
+  c.n = c0.n;
+  c.active = c0.active;
+  c.lane = opaque(c0.lane);
+  const bool is_push = (op <= OP_PUSH_ROWID) || (op >= OP_UTF8_EQ_LIT && op <= OP_UTF8_NE_COL);
+  const bool is_unary = op == OP_I64_TO_F64;
+  Slot a, b;
+  uint32_t dst;
+  if (is_push) {
+    dst = d;
 #pragma unroll
-  for (int j = 0; j < VM_R; ++j) a.v[j] = d2u((double)(int64_t)a.v[j]);
+    for (int j = 0; j < VM_R; ++j) a.v[j] = 0, b.v[j] = 0;
+    a.valid = b.valid = 0xFu;
+  } else if (is_unary) {
+    dst = d - 1;
+    slot_get(S, d - 1, a);
+    slot_copy(b, a);
+  } else {
+    dst = d - 2;
+    slot_get(S, d - 2, a);
+    slot_get(S, d - 1, b);
+  }
+  switch (op) {
+    case OP_PUSH_COL64:
+    case OP_PUSH_COL32: {
+      // columns beyond the cache: one round trip per use
+      const VmCol &col = P.cols[arg];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool on = ((c.active >> (2 * h)) & 3u) != 0;
+        const int64_t r = c.row0 + h * 128 + 2 * (int64_t)c.lane;
+        uint64_t x = 0, y = 0;
+        if (on) {
+          if (op == OP_PUSH_COL64) {
+            U64x2 t = *(const U64x2 *)((const uint64_t *)col.values + r);
+            x = t.x;
+            y = t.y;
+          } else {
+            U32x2 t = *(const U32x2 *)((const uint32_t *)col.values + r);
+            x = (uint64_t)(int64_t)(int32_t)t.x;
+            y = (uint64_t)(int64_t)(int32_t)t.y;
+          }
+        }
+        a.v[2 * h] = x;
+        a.v[2 * h + 1] = y;
+      }
+      a.valid = col.validity ? load_bits4(col.validity, c) : 0xFu;
+      break;
+    }
+    case OP_PUSH_COLBOOL: {
+      const VmCol &col = P.cols[arg];
+      uint32_t bits = load_bits4((const uint8_t *)col.values, c);
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) a.v[j] = (bits >> j) & 1u;
+      a.valid = col.validity ? load_bits4(col.validity, c) : 0xFu;
+      break;
+    }
+    case OP_PUSH_ROWID: {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) a.v[j] = (uint64_t)(c.row0 + (j >> 1) * 128 + 2 * (int64_t)c.lane + (j & 1));
+      break;
+    }
+    case OP_UTF8_EQ_LIT:
+    case OP_UTF8_NE_LIT:
+    case OP_UTF8_EQ_COL:
+    case OP_UTF8_NE_COL: {
+      const bool vs_lit = op == OP_UTF8_EQ_LIT || op == OP_UTF8_NE_LIT;
+      const bool want_eq = op == OP_UTF8_EQ_LIT || op == OP_UTF8_EQ_COL;
+      const VmCol &ca = P.cols[arg & 0xffu];
+      const uint32_t second = (arg >> 8) & 0xffu;
+      const uint8_t *lit = vs_lit ? (const uint8_t *)P.lits[second] : nullptr;
+      const int32_t llen = vs_lit ? (int32_t)P.lits[second + 1] : 0;
+      const VmCol &cb = P.cols[vs_lit ? 0 : second];
+      uint32_t act = c.active;
+      // rolled over the four rows: row j = (it>>1)*128 + (it&1) ahead of the lane's first row
+#pragma unroll 1
+      for (int it = 0; it < VM_R; ++it) {
+        uint64_t res = 0;
+        if (act & 1u) {
+          int64_t r = c.row0 + (it >> 1) * 128 + 2 * (int64_t)c.lane + (it & 1);
+          int32_t a0 = ca.offsets[r], a1 = ca.offsets[r + 1];
+          bool eq;
+          if (vs_lit) {
+            eq = (a1 - a0 == llen) && utf8_equal((const uint8_t *)ca.values + a0, lit, llen);
+          } else {
+            int32_t b0 = cb.offsets[r], b1 = cb.offsets[r + 1];
+            eq = (a1 - a0 == b1 - b0) && utf8_equal((const uint8_t *)ca.values + a0, (const uint8_t *)cb.values + b0, a1 - a0);
+          }
+          res = (eq == want_eq) ? 1u : 0u;
+        }
+        a.v[0] = res;
+        QE_ROT4(a.v);
+        act = rot4(act);
+      }
+      uint32_t va = ca.validity ? load_bits4(ca.validity, c) : 0xFu;
+      uint32_t vb = (!vs_lit && cb.validity) ? load_bits4(cb.validity, c) : 0xFu;
+      a.valid = va & vb;
+      break;
+    }
+    case OP_SWAP: {
+      slot_put(S, d - 1, a);
+      slot_copy(a, b);
+      break;
+    }
+    case OP_I64_TO_F64: {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) a.v[j] = d2u((double)(int64_t)a.v[j]);
+      break;
+    }
+    case OP_DIV_F64: {
+#pragma unroll 1
+      for (int it = 0; it < VM_R; ++it) {
+        a.v[0] = d2u(u2d(a.v[0]) / u2d(b.v[0]));
+        QE_ROT4(a.v);
+        QE_ROT4(b.v);
+      }
+      a.valid &= b.valid;
+      break;
+    }
+    case OP_DIV_I32:
+    case OP_MOD_I32:
+    case OP_DIV_I64:
+    case OP_MOD_I64: {
+      // int32 operands are sign-extended, so one 64-bit division serves both widths; only the
+      // overflow case (MIN / -1) depends on the width.  x/0, x%0 and MIN/-1 panic in the
+      // reference; here they give null.
+      const bool w32 = op == OP_DIV_I32 || op == OP_MOD_I32;
+      const bool want_mod = op == OP_MOD_I32 || op == OP_MOD_I64;
+      const int64_t tmin = w32 ? (int64_t)INT32_MIN : INT64_MIN;
+      uint32_t valid = a.valid & b.valid;
+#pragma unroll 1
+      for (int it = 0; it < VM_R; ++it) {
+        int64_t x = (int64_t)a.v[0], y = (int64_t)b.v[0];
+        int64_t r = 0;
+        if (y == 0 || (x == tmin && y == -1)) {
+          valid &= ~1u;
+        } else {
+          int64_t q = x / y;
+          r = want_mod ? x - q * y : q;
+        }
+        a.v[0] = (uint64_t)r;
+        QE_ROT4(a.v);
+        QE_ROT4(b.v);
+        valid = rot4(valid);
+      }
+      a.valid = valid;
+      break;
+    }
+    default:
+      break;
+  }
+  slot_put(S, dst, a);
 }
 
 // Runs the postfix code starting at `pc` until OP_END; the value is left in S[0].
-// Control flow depends only on the (wave-uniform) instruction words.
-__device__ __forceinline__ void vm_eval(const VmProgram &P, uint32_t pc, const RowCtx &c, Slot (&S)[VM_MAX_DEPTH]) {
+// Control flow depends only on the (wave-uniform) instruction words.  FULL = false leaves out
+// vm_slow (division, utf8, uncached columns, casts): the host picks that variant when a program
+// has none of those, and it needs far fewer registers.
+template <bool FULL>
+__device__ __forceinline__ void vm_eval(const VmProgram &P, const ProgRegs &R, uint32_t pc, const RowCtx &c,
+                                        const ColCache &K, Slot (&S)[VM_MAX_DEPTH]) {
   for (;;) {
-    uint32_t ins = P.insn[pc++];
+    uint32_t ins = fetch_insn(R, pc++);
     uint32_t op = ins & 0xffu;
     if (op == OP_END) break;
     uint32_t d = (ins >> 8) & 0xfu;
     uint32_t arg = ins >> 12;
-    bool is_push = (op <= OP_PUSH_ROWID) || (op >= OP_UTF8_EQ_LIT && op <= OP_UTF8_NE_COL);
-    if (is_push) {
+    if (op_is_fast_binary(op)) {
       switch (d) {
-        case 0: vm_push(op, arg, P, c, S[0]); break;
-        case 1: vm_push(op, arg, P, c, S[1]); break;
-        case 2: vm_push(op, arg, P, c, S[2]); break;
-        default: vm_push(op, arg, P, c, S[3]); break;
+        case 2: vm_binary_fast(op, S[0], S[1]); break;
+        case 3: vm_binary_fast(op, S[1], S[2]); break;
+        default: vm_binary_fast(op, S[2], S[3]); break;
       }
-    } else if (op == OP_SWAP) {
+    } else if (op_is_fast_push(op)) {
       switch (d) {
-        case 2: vm_swap(S[0], S[1]); break;
-        case 3: vm_swap(S[1], S[2]); break;
-        default: vm_swap(S[2], S[3]); break;
+        case 0: vm_push_fast(op, arg, R, K, S[0]); break;
+        case 1: vm_push_fast(op, arg, R, K, S[1]); break;
+        case 2: vm_push_fast(op, arg, R, K, S[2]); break;
+        default: vm_push_fast(op, arg, R, K, S[3]); break;
       }
-    } else if (op == OP_I64_TO_F64) {
-      switch (d) {
-        case 1: vm_i64_to_f64(S[0]); break;
-        case 2: vm_i64_to_f64(S[1]); break;
-        case 3: vm_i64_to_f64(S[2]); break;
-        default: vm_i64_to_f64(S[3]); break;
-      }
-    } else {
-      switch (d) {
-        case 2: vm_binary(op, S[0], S[1]); break;
-        case 3: vm_binary(op, S[1], S[2]); break;
-        default: vm_binary(op, S[2], S[3]); break;
-      }
+    } else if constexpr (FULL) {
+      vm_slow(op, d, arg, P, c, K, S);
     }
   }
 }
@@ -351,6 +537,7 @@ __device__ __forceinline__ void store_bitmap256(uint32_t *words, const RowCtx &c
   }
 }
 
+// Output buffers are allocated by the library with slack, so a row pair is always one store.
 __device__ __forceinline__ void store_dense(const VmOut &o, const RowCtx &c, const Slot &s) {
   uint32_t inr = in_range_bits(c.row0, c.lane, c.n);
   if (o.type == VT_BOOL) {
@@ -360,13 +547,11 @@ __device__ __forceinline__ void store_dense(const VmOut &o, const RowCtx &c, con
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       int64_t r = c.row0 + h * 128 + 2 * (int64_t)c.lane;
-      if (r + 1 < c.n) {
+      if (r < c.n) {
         U32x2 t;
         t.x = (uint32_t)s.v[2 * h];
         t.y = (uint32_t)s.v[2 * h + 1];
         *(U32x2 *)(p + r) = t;
-      } else if (r < c.n) {
-        p[r] = (uint32_t)s.v[2 * h];
       }
     }
   } else {
@@ -374,13 +559,11 @@ __device__ __forceinline__ void store_dense(const VmOut &o, const RowCtx &c, con
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       int64_t r = c.row0 + h * 128 + 2 * (int64_t)c.lane;
-      if (r + 1 < c.n) {
+      if (r < c.n) {
         U64x2 t;
         t.x = s.v[2 * h];
         t.y = s.v[2 * h + 1];
         *(U64x2 *)(p + r) = t;
-      } else if (r < c.n) {
-        p[r] = s.v[2 * h];
       }
     }
   }
@@ -388,11 +571,13 @@ __device__ __forceinline__ void store_dense(const VmOut &o, const RowCtx &c, con
 }
 
 // --------------------------------------------------------- projection kernel
-__global__ __launch_bounds__(VM_BLOCK_THREADS) void qe_project_kernel(const ProjectArgs A) {
+template <bool FULL>
+__global__ __launch_bounds__(VM_BLOCK_THREADS, FULL ? 2 : 3) void qe_project_kernel(const ProjectArgs A) {
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   const int64_t n = A.n_rows;
   const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
+  const ProgRegs R = prog_regs(A.prog, lane);
   for (int64_t ws = (int64_t)blockIdx.x * VM_BLOCK_WAVES + wave; ws < nsteps;
        ws += (int64_t)gridDim.x * VM_BLOCK_WAVES) {
     RowCtx c;
@@ -400,9 +585,12 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS) void qe_project_kernel(const Proj
     c.n = n;
     c.lane = lane;
     c.active = in_range_bits(c.row0, lane, n);
+    ColCache K;
+    cache_load(A.prog, (1u << A.prog.cache_n) - 1u, c, K);
+#pragma unroll 1
     for (int e = 0; e < A.n_outs; ++e) {
       Slot S[VM_MAX_DEPTH];
-      vm_eval(A.prog, A.outs[e].pc, c, S);
+      vm_eval<FULL>(A.prog, R, A.outs[e].pc, c, K, S);
       store_dense(A.outs[e], c, S[0]);
     }
   }
@@ -413,6 +601,7 @@ constexpr unsigned long long ST_FLAG_AGG = 1ull << 62;
 constexpr unsigned long long ST_FLAG_PREFIX = 2ull << 62;
 constexpr unsigned long long ST_VALUE_MASK = (1ull << 62) - 1;
 constexpr int LOOKBACK_SPIN_LIMIT = 1 << 22;
+static_assert(FILTER_STEPS == 4, "the filter kernel selects among four per-step prefixes");
 
 __device__ __forceinline__ unsigned long long ld_status(const unsigned long long *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -489,9 +678,8 @@ __device__ __forceinline__ void rank_rows(uint32_t sel, uint32_t (&rank)[VM_R]) 
   rank[3] = c0 + lt1 + ((sel >> 2) & 1u);
 }
 
-__device__ __forceinline__ void store_compact(const VmOut &o, unsigned long long base, uint32_t sel, const Slot &s) {
-  uint32_t rank[VM_R];
-  rank_rows(sel, rank);
+__device__ __forceinline__ void store_compact(const VmOut &o, unsigned long long base, uint32_t sel,
+                                              const uint32_t (&rank)[VM_R], const Slot &s) {
 #pragma unroll
   for (int j = 0; j < VM_R; ++j) {
     if ((sel >> j) & 1u) {
@@ -508,12 +696,14 @@ __device__ __forceinline__ void store_compact(const VmOut &o, unsigned long long
   }
 }
 
-// One ticket = one tile of 4096 rows.  Phase 1 evaluates the predicate for the tile and keeps
-// the 16 selection bits of each lane in a register; the tile's count goes through the look-back;
-// phase 2 evaluates each output expression for the selected rows only and writes it at its final
-// position.  Rows keep their input order (the reference's filter_chunk is order preserving,
-// tests/mod.rs:138-188), and a row whose predicate is null is dropped.
-__global__ __launch_bounds__(VM_BLOCK_THREADS) void qe_filter_kernel(const FilterArgs A) {
+// One ticket = one tile of 4096 rows = 4 steps of 1024.  Sub-steps 0..3 evaluate the predicate
+// of each step and keep the 16 selection bits of each lane in a register; then the tile's count
+// goes through the look-back; sub-steps 4..7 evaluate every output expression for the selected
+// rows only and write it at its final position.  Rows keep their input order (the reference's
+// filter_chunk is order preserving, tests/mod.rs:138-188); a row whose predicate is null is
+// dropped.  Both phases run through one loop body so that the interpreter exists once.
+template <bool FULL>
+__global__ __launch_bounds__(VM_BLOCK_THREADS, FULL ? 2 : 3) void qe_filter_kernel(const FilterArgs A) {
   __shared__ unsigned long long s_tile;
   __shared__ unsigned long long s_base;
   __shared__ uint32_t s_cnt[FILTER_STEPS * VM_BLOCK_WAVES];
@@ -521,6 +711,7 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS) void qe_filter_kernel(const Filte
   const uint32_t wave = threadIdx.x >> 6;
   const int64_t n = A.n_rows;
   unsigned long long *status = (unsigned long long *)(A.scratch + 1);
+  const ProgRegs R = prog_regs(A.prog, lane);
 
   for (;;) {
     if (threadIdx.x == 0) s_tile = atomicAdd(&A.scratch->ticket, 1ull);
@@ -530,55 +721,60 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS) void qe_filter_kernel(const Filte
     const int64_t tile_row0 = tile * FILTER_TILE_ROWS;
 
     uint32_t mask = 0;
+    uint32_t pref[FILTER_STEPS] = {0, 0, 0, 0};
+    unsigned long long base = 0;
+#pragma unroll 1
+    for (int u = 0; u < 2 * FILTER_STEPS; ++u) {
+      const bool phase2 = u >= FILTER_STEPS;
+      const int s = u & (FILTER_STEPS - 1);
+      if (u == FILTER_STEPS) {
+        // all four counts of every wave are in: prefix inside the tile, then across tiles
+        __syncthreads();
+        uint32_t run = 0;
 #pragma unroll
-    for (int s = 0; s < FILTER_STEPS; ++s) {
+        for (int i = 0; i < FILTER_STEPS * VM_BLOCK_WAVES; ++i) {
+          if ((uint32_t)(i & (VM_BLOCK_WAVES - 1)) == wave) pref[i / VM_BLOCK_WAVES] = run;
+          run += s_cnt[i];
+        }
+        if (wave == 0) {
+          unsigned long long excl = lookback_exclusive(status, tile, run, lane, &A.scratch->error);
+          if (lane == 0) {
+            s_base = excl;
+            if (tile == A.n_tiles - 1) A.scratch->total = excl + run;
+          }
+        }
+        __syncthreads();
+        base = s_base;
+      }
       RowCtx c;
       c.row0 = tile_row0 + s * VM_BLOCK_ROWS + wave * VM_WAVE_ROWS;
       c.n = n;
       c.lane = lane;
-      c.active = in_range_bits(c.row0, lane, n);
+      c.active = phase2 ? ((mask >> (4 * s)) & 0xFu) : in_range_bits(c.row0, lane, n);
+      const bool any = __ballot(c.active != 0) != 0;
       uint32_t sel = 0;
-      if (c.row0 < n) {
-        Slot S[VM_MAX_DEPTH];
-        vm_eval(A.prog, A.pred_pc, c, S);
-        sel = c.active & S[0].valid & bool_bits(S[0]);
+      if (any) {
+        // phase 2 loads for the selected rows only: unselected lanes issue no load
+        ColCache K;
+        cache_load(A.prog, phase2 ? A.out_cache_mask : A.pred_cache_mask, c, K);
+        uint32_t rank[VM_R];
+        if (phase2) rank_rows(c.active, rank);
+        const unsigned long long obase = base + (s == 0 ? pref[0] : s == 1 ? pref[1] : s == 2 ? pref[2] : pref[3]);
+        const int ntask = phase2 ? A.n_outs : 1;
+#pragma unroll 1
+        for (int e = 0; e < ntask; ++e) {
+          Slot S[VM_MAX_DEPTH];
+          vm_eval<FULL>(A.prog, R, phase2 ? A.outs[e].pc : A.pred_pc, c, K, S);
+          if (phase2)
+            store_compact(A.outs[e], obase, c.active, rank, S[0]);
+          else
+            sel = c.active & S[0].valid & bool_bits(S[0]);
+        }
       }
-      mask |= sel << (4 * s);
-      uint32_t cnt = popc_sel(sel);
-      if (lane == 0) s_cnt[s * VM_BLOCK_WAVES + wave] = cnt;
-    }
-    __syncthreads();
-
-    uint32_t pref[FILTER_STEPS];
-    uint32_t run = 0;
-#pragma unroll
-    for (int i = 0; i < FILTER_STEPS * VM_BLOCK_WAVES; ++i) {
-      if ((uint32_t)(i & (VM_BLOCK_WAVES - 1)) == wave) pref[i / VM_BLOCK_WAVES] = run;
-      run += s_cnt[i];
-    }
-    if (wave == 0) {
-      unsigned long long excl = lookback_exclusive(status, tile, run, lane, &A.scratch->error);
-      if (lane == 0) {
-        s_base = excl;
-        if (tile == A.n_tiles - 1) A.scratch->total = excl + run;
-      }
-    }
-    __syncthreads();
-    const unsigned long long base = s_base;
-
-    for (int e = 0; e < A.n_outs; ++e) {
-#pragma unroll
-      for (int s = 0; s < FILTER_STEPS; ++s) {
-        uint32_t sel = (mask >> (4 * s)) & 0xFu;
-        if (__ballot(sel != 0) == 0) continue;
-        RowCtx c;
-        c.row0 = tile_row0 + s * VM_BLOCK_ROWS + wave * VM_WAVE_ROWS;
-        c.n = n;
-        c.lane = lane;
-        c.active = sel;
-        Slot S[VM_MAX_DEPTH];
-        vm_eval(A.prog, A.outs[e].pc, c, S);
-        store_compact(A.outs[e], base + pref[s], sel, S[0]);
+      if (!phase2) {
+        mask |= sel << (4 * s);
+        uint32_t cnt = popc_sel(sel);
+        if (lane == 0) s_cnt[s * VM_BLOCK_WAVES + wave] = cnt;
       }
     }
   }
@@ -647,14 +843,22 @@ __device__ __forceinline__ int64_t global_find_or_claim(const AggTable &T, uint6
   return -1;
 }
 
-// >= 0: LDS slot; < 0 and != SLOT_NONE: ~global slot; SLOT_NONE: table full.
-__device__ __forceinline__ int32_t find_or_claim(const LdsTable &L, const AggTable &T, uint64_t key) {
-  uint64_t h = mix64(key);
+// Cheap 32-bit hash for the LDS table (the global table uses the full mix64).
+__device__ __forceinline__ uint32_t hash32(uint64_t key) {
+  uint32_t h = (uint32_t)key * 0x9E3779B1u ^ (uint32_t)(key >> 32) * 0x85EBCA77u;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 13;
+  return h;
+}
+
+// LDS slot of `key` (claiming one if new), or -1 when the key does not fit the LDS table.
+__device__ __forceinline__ int32_t lds_find_or_claim(const LdsTable &L, uint64_t key) {
   if (key == AGG_EMPTY_KEY) {
-    if (atomicCAS(&L.keys[L.cap], AGG_EMPTY_KEY, 0ull) == AGG_EMPTY_KEY) {}
+    (void)atomicCAS(&L.keys[L.cap], AGG_EMPTY_KEY, 0ull);
     return (int32_t)L.cap;
   }
-  uint32_t s = (uint32_t)h & (L.cap - 1);
+  uint32_t s = hash32(key) & (L.cap - 1);
   for (int p = 0; p < LDS_MAX_PROBE; ++p) {
     unsigned long long cur = *(volatile unsigned long long *)&L.keys[s];
     if (cur == key) return (int32_t)s;
@@ -669,25 +873,15 @@ __device__ __forceinline__ int32_t find_or_claim(const LdsTable &L, const AggTab
     }
     s = (s + 1) & (L.cap - 1);
   }
-  int64_t g = global_find_or_claim(T, key, h);
-  if (g < 0) return SLOT_NONE;
-  return (int32_t)~(uint32_t)g;
+  return -1;
 }
 
-__device__ __forceinline__ void lds_acc_apply(unsigned long long *p, uint32_t op, uint64_t v) {
+__device__ __forceinline__ void acc_apply(unsigned long long *p, uint32_t op, uint64_t v) {
   switch (op) {
     case ACC_SUM_F64: atomicAdd((double *)p, u2d(v)); break;
     case ACC_MIN: atomicMin(p, (unsigned long long)v); break;
     case ACC_MAX: atomicMax(p, (unsigned long long)v); break;
     default: atomicAdd(p, (unsigned long long)v); break;  // ACC_SUM_I64, ACC_COUNT
-  }
-}
-__device__ __forceinline__ void global_acc_apply(unsigned long long *p, uint32_t op, uint64_t v) {
-  switch (op) {
-    case ACC_SUM_F64: atomicAdd((double *)p, u2d(v)); break;
-    case ACC_MIN: atomicMin(p, (unsigned long long)v); break;
-    case ACC_MAX: atomicMax(p, (unsigned long long)v); break;
-    default: atomicAdd(p, (unsigned long long)v); break;
   }
 }
 
@@ -701,40 +895,30 @@ __device__ __forceinline__ uint64_t acc_combine(uint32_t op, uint64_t a, uint64_
 }
 
 __device__ __forceinline__ uint64_t wave_reduce_acc(uint32_t op, uint64_t v) {
-#pragma unroll
+#pragma unroll 1
   for (int o = 32; o > 0; o >>= 1) v = acc_combine(op, v, (uint64_t)__shfl_xor((unsigned long long)v, o));
   return v;
 }
 
-__device__ __forceinline__ void apply_slot(const LdsTable &L, const AggTable &T, int32_t slot, int a, uint32_t op,
-                                           uint64_t v) {
-  if (slot >= 0)
-    lds_acc_apply(&L.acc[a * L.stride + slot], op, v);
-  else
-    global_acc_apply(&T.acc[(uint64_t)a * T.stride + (uint32_t)~slot], op, v);
-}
-__device__ __forceinline__ void apply_nn(const LdsTable &L, const AggTable &T, int32_t slot, int a, uint32_t cnt) {
-  if (slot >= 0)
-    atomicAdd(&L.nn[a * L.stride + slot], cnt);
-  else
-    atomicAdd(&T.nn[(uint64_t)a * T.stride + (uint32_t)~slot], (unsigned long long)cnt);
-}
-__device__ __forceinline__ void apply_rowcnt(const LdsTable &L, const AggTable &T, int32_t slot, uint32_t cnt) {
-  if (slot >= 0)
-    atomicAdd(&L.rowcnt[slot], cnt);
-  else
-    atomicAdd(&T.rowcnt[(uint32_t)~slot], (unsigned long long)cnt);
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
+  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, lane);
+  uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), lane);
+  return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-constexpr int LEADER_ROUNDS = 2;
 constexpr uint32_t LEADER_MIN_ROWS = 24;
+constexpr int LEADER_TRIES = 2;
+constexpr int32_t SLOT_LDS_MISS = -1;  // transient: the row still needs a global slot
 
 // Each workgroup folds its rows into an LDS hash table (keys claimed by 64-bit LDS compare-swap,
 // accumulators updated by LDS atomics) and flushes the table into the global open-addressing
 // table once, at the end.  Keys that do not fit the LDS table go straight to the global table.
 // A key that dominates a wave-step (low cardinality, skew) is reduced across the wave first, so
 // that it costs one atomic per wave-step instead of one per row.
-__global__ __launch_bounds__(VM_BLOCK_THREADS) void qe_aggregate_kernel(const AggArgs A) {
+//
+// Slot encoding per row: >= 0 LDS slot; <= -2: global slot g stored as -2 - g; SLOT_NONE: dropped.
+template <bool FULL>
+__global__ __launch_bounds__(VM_BLOCK_THREADS, FULL ? 2 : 3) void qe_aggregate_kernel(const AggArgs A) {
   extern __shared__ unsigned long long lds_raw[];
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
@@ -762,6 +946,15 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS) void qe_aggregate_kernel(const Ag
   if (threadIdx.x == 0) *L.used = 0;
   __syncthreads();
 
+  // wave-uniform descriptors, one per lane (see ProgRegs): task list, key fields, accumulators
+  const ProgRegs R = prog_regs(A.prog, lane);
+  const uint32_t tl = lane < VM_MAX_TASKS ? lane : 0;
+  const uint32_t task_pc = A.tasks[tl].pc;
+  const uint32_t task_w = (uint32_t)A.tasks[tl].role | ((uint32_t)A.tasks[tl].idx << 8) | ((uint32_t)A.tasks[tl].has_eval << 16);
+  const uint32_t key_w = (uint32_t)A.keys[lane & (VM_MAX_KEYS - 1)].shift | ((uint32_t)A.keys[lane & (VM_MAX_KEYS - 1)].bits << 8);
+  const uint32_t acc_w = (uint32_t)A.accs[lane & (VM_MAX_ACCS - 1)].op | ((uint32_t)A.accs[lane & (VM_MAX_ACCS - 1)].in_type << 8) |
+                         ((uint32_t)A.accs[lane & (VM_MAX_ACCS - 1)].track_nn << 16);
+
   const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
   for (int64_t ws = (int64_t)blockIdx.x * VM_BLOCK_WAVES + wave; ws < nsteps;
        ws += (int64_t)gridDim.x * VM_BLOCK_WAVES) {
@@ -770,86 +963,124 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS) void qe_aggregate_kernel(const Ag
     c.n = n;
     c.lane = lane;
     c.active = in_range_bits(c.row0, lane, n);
-    Slot S[VM_MAX_DEPTH];
-
-    if (A.has_pred) {
-      vm_eval(A.prog, A.pred_pc, c, S);
-      c.active &= S[0].valid & bool_bits(S[0]);
-    }
-    if (__ballot(c.active != 0) == 0) continue;
+    ColCache K;
+    cache_load(A.prog, (1u << A.prog.cache_n) - 1u, c, K);
 
     uint64_t key[VM_R] = {0, 0, 0, 0};
-    for (int k = 0; k < A.n_keys; ++k) {
-      vm_eval(A.prog, A.keys[k].pc, c, S);
-      c.active &= S[0].valid;  // a null key drops the row (physical_plan/mod.rs:367)
-      uint64_t fmask = A.keys[k].bits >= 64 ? ~0ull : ((1ull << A.keys[k].bits) - 1ull);
-      uint32_t sh = A.keys[k].shift;
-#pragma unroll
-      for (int j = 0; j < VM_R; ++j) key[j] |= (S[0].v[j] & fmask) << sh;
-    }
+    int32_t slot[VM_R] = {SLOT_NONE, SLOT_NONE, SLOT_NONE, SLOT_NONE};
+    uint32_t rem = 0;      // rows folded one by one
+    uint32_t lead_mb = 0;  // rows folded through the wave reduction
+    int32_t lead_slot = SLOT_NONE;
 
-    // ---- wave-level combining of dominant keys
-    uint32_t rem = c.active;
-    uint32_t lead_mb[LEADER_ROUNDS];
-    int32_t lead_slot[LEADER_ROUNDS];
-    int n_lead = 0;
+#pragma unroll 1
+    for (int t = 0; t < A.n_tasks; ++t) {
+      const uint32_t tw = (uint32_t)__builtin_amdgcn_readlane((int)task_w, t);
+      const uint32_t role = tw & 0xffu;
+      const uint32_t idx = (tw >> 8) & 0xffu;
+      Slot S[VM_MAX_DEPTH];
+      S[0].valid = 0xFu;
 #pragma unroll
-    for (int rd = 0; rd < LEADER_ROUNDS; ++rd) {
-      lead_mb[rd] = 0;
-      lead_slot[rd] = SLOT_NONE;
-    }
-#pragma unroll
-    for (int rd = 0; rd < LEADER_ROUNDS; ++rd) {
-      if (n_lead != rd) break;
-      uint64_t ball = __ballot(rem != 0);
-      if (ball == 0) break;
-      int src = __builtin_ctzll(ball);
-      uint64_t kl = (rem & 1u) ? key[0] : (rem & 2u) ? key[1] : (rem & 4u) ? key[2] : key[3];
-      uint64_t k0 = (uint64_t)__shfl((unsigned long long)kl, src);
-      uint32_t mb = 0;
-#pragma unroll
-      for (int j = 0; j < VM_R; ++j)
-        if (((rem >> j) & 1u) && key[j] == k0) mb |= 1u << j;
-      uint32_t cnt = popc_sel(mb);
-      if (cnt < LEADER_MIN_ROWS) break;
-      int32_t sl = 0;
-      if ((int)lane == src) {
-        sl = find_or_claim(L, A.table, k0);
-        if (sl != SLOT_NONE) apply_rowcnt(L, A.table, sl, cnt);
-      }
-      sl = __shfl(sl, src);
-      rem &= ~mb;
-      if (sl != SLOT_NONE) {
-        lead_mb[rd] = mb;
-        lead_slot[rd] = sl;
-      }
-      n_lead = rd + 1;
-    }
+      for (int j = 0; j < VM_R; ++j) S[0].v[j] = 1;
+      if ((tw >> 16) & 1u) vm_eval<FULL>(A.prog, R, (uint32_t)__builtin_amdgcn_readlane((int)task_pc, t), c, K, S);
 
-    // ---- slot of every remaining row
-    int32_t slot[VM_R];
+      if (role == ROLE_PRED) {
+        c.active &= S[0].valid & bool_bits(S[0]);
+        if (__ballot(c.active != 0) == 0) break;  // nothing of this wave-step survives the filter
+      } else if (role == ROLE_KEY) {
+        c.active &= S[0].valid;  // a null key drops the row (physical_plan/mod.rs:367)
+        const uint32_t kw = (uint32_t)__builtin_amdgcn_readlane((int)key_w, (int)idx);
+        const uint32_t kbits = (kw >> 8) & 0xffu;
+        const uint64_t fmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
+        const uint32_t sh = kw & 0xffu;
 #pragma unroll
-    for (int j = 0; j < VM_R; ++j) {
-      slot[j] = SLOT_NONE;
-      if ((rem >> j) & 1u) {
-        slot[j] = find_or_claim(L, A.table, key[j]);
-        if (slot[j] == SLOT_NONE)
-          rem &= ~(1u << j);
-        else
-          apply_rowcnt(L, A.table, slot[j], 1u);
-      }
-    }
-
-    // ---- accumulators, one at a time
-    for (int a = 0; a < n_accs; ++a) {
-      const uint32_t op = A.accs[a].op;
-      const uint32_t in_type = A.accs[a].in_type;
-      uint32_t valid = 0xFu;
-      uint64_t v[VM_R];
-      if (A.accs[a].has_input) {
-        RowCtx ca = c;  // rows dropped by a null key need no input either
-        vm_eval(A.prog, A.accs[a].pc, ca, S);
-        valid = S[0].valid;
+        for (int j = 0; j < VM_R; ++j) key[j] |= (S[0].v[j] & fmask) << sh;
+      } else if (role == ROLE_LOOKUP) {
+        rem = c.active;
+        // ---- a key that dominates the wave-step?  Try the first row of up to two lanes.
+        uint64_t ball = __ballot(rem != 0);
+        uint64_t k0 = 0;
+        uint32_t lead_cnt = 0;
+        int src = 0;
+#pragma unroll 1
+        for (int tr = 0; tr < LEADER_TRIES && ball != 0; ++tr) {
+          src = __builtin_ctzll(ball);
+          const uint64_t kl = (rem & 1u) ? key[0] : (rem & 2u) ? key[1] : (rem & 4u) ? key[2] : key[3];
+          k0 = readlane64(kl, src);
+          uint32_t mb = 0;
+#pragma unroll
+          for (int j = 0; j < VM_R; ++j)
+            if (((rem >> j) & 1u) && key[j] == k0) mb |= 1u << j;
+          const uint32_t cnt = popc_sel(mb);
+          if (cnt >= LEADER_MIN_ROWS) {
+            lead_mb = mb;
+            lead_cnt = cnt;
+            break;
+          }
+          ball &= ~__ballot(mb != 0);  // next candidate: a lane none of whose rows matched
+        }
+        rem &= ~lead_mb;
+        // ---- LDS slots: the dominant key (one lane) and the remaining rows, back to back
+        int32_t lsl = SLOT_NONE;
+        if (lead_cnt != 0 && (int)lane == src) lsl = lds_find_or_claim(L, k0);
+#pragma unroll
+        for (int j = 0; j < VM_R; ++j) {
+          slot[j] = SLOT_NONE;
+          if ((rem >> j) & 1u) slot[j] = lds_find_or_claim(L, key[j]);
+        }
+        // ---- keys the LDS table has no room for go to the global table (rare: rolled loop)
+        uint32_t miss = 0;
+#pragma unroll
+        for (int j = 0; j < VM_R; ++j)
+          if (slot[j] == SLOT_LDS_MISS) miss |= 1u << j;
+        const bool lead_miss = lsl == SLOT_LDS_MISS;
+        if (__ballot(miss != 0 || lead_miss) != 0) {
+#pragma unroll 1
+          for (int it = 0; it <= VM_R; ++it) {
+            const bool lead_it = it == 0;
+            const bool act = lead_it ? lead_miss : ((miss & 1u) != 0);
+            const uint64_t kcur = lead_it ? k0 : key[0];
+            int32_t sl = lead_it ? lsl : slot[0];
+            if (act) {
+              int64_t g = global_find_or_claim(A.table, kcur, mix64(kcur));
+              sl = g < 0 ? SLOT_NONE : (int32_t)(-2 - (int32_t)g);
+            }
+            if (lead_it) {
+              lsl = sl;
+            } else {
+              slot[0] = sl;
+              miss = rot4(miss);
+              QE_ROT4(key);
+              QE_ROT4(slot);
+            }
+          }
+        }
+        // ---- row counts
+        if (lead_cnt != 0 && (int)lane == src && lsl != SLOT_NONE) {
+          if (lsl >= 0)
+            atomicAdd(&L.rowcnt[lsl], lead_cnt);
+          else
+            atomicAdd(&A.table.rowcnt[(uint32_t)(-2 - lsl)], (unsigned long long)lead_cnt);
+        }
+        lead_slot = lead_cnt != 0 ? __builtin_amdgcn_readlane(lsl, src) : SLOT_NONE;
+        if (lead_slot == SLOT_NONE) lead_mb = 0;
+#pragma unroll
+        for (int j = 0; j < VM_R; ++j) {
+          if ((rem >> j) & 1u) {
+            if (slot[j] >= 0)
+              atomicAdd(&L.rowcnt[slot[j]], 1u);
+            else if (slot[j] != SLOT_NONE)
+              atomicAdd(&A.table.rowcnt[(uint32_t)(-2 - slot[j])], 1ull);
+            else
+              rem &= ~(1u << j);  // the global table is full: the host grows it and runs again
+          }
+        }
+      } else {  // ROLE_ACC
+        const uint32_t aw = (uint32_t)__builtin_amdgcn_readlane((int)acc_w, (int)idx);
+        const uint32_t op = aw & 0xffu;
+        const uint32_t in_type = (aw >> 8) & 0xffu;
+        const bool track = ((aw >> 16) & 0xffu) != 0;
+        uint32_t valid = S[0].valid;
+        uint64_t v[VM_R];
 #pragma unroll
         for (int j = 0; j < VM_R; ++j) {
           uint64_t x = S[0].v[j];
@@ -861,34 +1092,41 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS) void qe_aggregate_kernel(const Ag
           }
           v[j] = x;
         }
-      } else {
+        unsigned long long *lacc = L.acc + idx * L.stride;
+        unsigned long long *gacc = A.table.acc + (uint64_t)idx * A.table.stride;
+        // wave-reduced contribution of the dominant key
+        if (lead_slot != SLOT_NONE) {
+          const uint32_t m = lead_mb & valid;
+          uint64_t part = acc_identity(op);
 #pragma unroll
-        for (int j = 0; j < VM_R; ++j) v[j] = 1;
-      }
-      const bool track = A.accs[a].track_nn != 0;
-
-#pragma unroll
-      for (int rd = 0; rd < LEADER_ROUNDS; ++rd) {
-        if (rd >= n_lead) break;
-        if (lead_slot[rd] == SLOT_NONE) continue;
-        uint32_t m = lead_mb[rd] & valid;
-        uint64_t part = acc_identity(op);
-#pragma unroll
-        for (int j = 0; j < VM_R; ++j)
-          if ((m >> j) & 1u) part = acc_combine(op, part, v[j]);
-        part = wave_reduce_acc(op, part);
-        uint32_t cnt = popc_sel(m);
-        if (lane == 0 && cnt != 0) {
-          apply_slot(L, A.table, lead_slot[rd], a, op, part);
-          if (track) apply_nn(L, A.table, lead_slot[rd], a, cnt);
+          for (int j = 0; j < VM_R; ++j)
+            if ((m >> j) & 1u) part = acc_combine(op, part, v[j]);
+          part = wave_reduce_acc(op, part);
+          const uint32_t part_cnt = popc_sel(m);
+          if (lane == 0 && part_cnt != 0) {
+            if (lead_slot >= 0) {
+              acc_apply(lacc + lead_slot, op, part);
+              if (track) atomicAdd(&L.nn[idx * L.stride + lead_slot], part_cnt);
+            } else {
+              const uint32_t g = (uint32_t)(-2 - lead_slot);
+              acc_apply(gacc + g, op, part);
+              if (track) atomicAdd(&A.table.nn[(uint64_t)idx * A.table.stride + g], (unsigned long long)part_cnt);
+            }
+          }
         }
-      }
-      uint32_t m = rem & valid;
+        const uint32_t m = rem & valid;
 #pragma unroll
-      for (int j = 0; j < VM_R; ++j) {
-        if ((m >> j) & 1u) {
-          apply_slot(L, A.table, slot[j], a, op, v[j]);
-          if (track) apply_nn(L, A.table, slot[j], a, 1u);
+        for (int j = 0; j < VM_R; ++j) {
+          if ((m >> j) & 1u) {
+            if (slot[j] >= 0) {
+              acc_apply(lacc + slot[j], op, v[j]);
+              if (track) atomicAdd(&L.nn[idx * L.stride + slot[j]], 1u);
+            } else {
+              const uint32_t g = (uint32_t)(-2 - slot[j]);
+              acc_apply(gacc + g, op, v[j]);
+              if (track) atomicAdd(&A.table.nn[(uint64_t)idx * A.table.stride + g], 1ull);
+            }
+          }
         }
       }
     }
@@ -911,8 +1149,7 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS) void qe_aggregate_kernel(const Ag
     for (int a = 0; a < n_accs; ++a) {
       uint32_t op = A.accs[a].op;
       unsigned long long val = L.acc[a * L.stride + i];
-      if (val != acc_identity(op) || op == ACC_SUM_F64)
-        global_acc_apply(&A.table.acc[(uint64_t)a * A.table.stride + g], op, val);
+      if (val != acc_identity(op) || op == ACC_SUM_F64) acc_apply(&A.table.acc[(uint64_t)a * A.table.stride + g], op, val);
       uint32_t nn = L.nn[a * L.stride + i];
       if (nn) atomicAdd(&A.table.nn[(uint64_t)a * A.table.stride + g], (unsigned long long)nn);
     }
@@ -1123,6 +1360,18 @@ __global__ void qe_generate_kernel(int kind, uint64_t seed, int64_t row0, int64_
 }
 
 // ---------------------------------------------------------------- launchers
+// Does the program use an instruction only the FULL interpreter variant carries?
+static bool program_needs_full(const VmProgram &P) {
+  for (int i = 0; i < VM_MAX_INSN; ++i) {
+    uint32_t op = P.insn[i] & 0xffu;
+    bool fast = op == OP_END || op == OP_PUSH_LIT || op >= OP_PUSH_CACHED64 || (op >= OP_ADD_I32 && op <= OP_MUL_I32) ||
+                (op >= OP_ADD_I64 && op <= OP_MUL_I64) || (op >= OP_ADD_F64 && op <= OP_MUL_F64) ||
+                (op >= OP_EQ_I64 && op <= OP_OR);
+    if (!fast) return true;
+  }
+  return false;
+}
+
 static int grid_for(int64_t work_items, int per_block, int max_blocks) {
   int64_t b = (work_items + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -1133,7 +1382,10 @@ static int grid_for(int64_t work_items, int per_block, int max_blocks) {
 hipError_t launch_project(const ProjectArgs &args, const DeviceInfo &dev, hipStream_t stream) {
   if (args.n_rows <= 0 || args.n_outs <= 0) return hipSuccess;
   int grid = grid_for(args.n_rows, VM_BLOCK_ROWS, dev.cus * 8);
-  hipLaunchKernelGGL(qe_project_kernel, dim3(grid), dim3(VM_BLOCK_THREADS), 0, stream, args);
+  if (program_needs_full(args.prog))
+    hipLaunchKernelGGL(qe_project_kernel<true>, dim3(grid), dim3(VM_BLOCK_THREADS), 0, stream, args);
+  else
+    hipLaunchKernelGGL(qe_project_kernel<false>, dim3(grid), dim3(VM_BLOCK_THREADS), 0, stream, args);
   return hipGetLastError();
 }
 
@@ -1149,7 +1401,10 @@ hipError_t launch_filter_reset(FilterScratch *scratch, int64_t n_rows, hipStream
 hipError_t launch_filter(const FilterArgs &args, const DeviceInfo &dev, hipStream_t stream) {
   if (args.n_rows <= 0) return hipSuccess;
   int grid = grid_for(args.n_tiles, 1, dev.cus * 8);
-  hipLaunchKernelGGL(qe_filter_kernel, dim3(grid), dim3(VM_BLOCK_THREADS), 0, stream, args);
+  if (program_needs_full(args.prog))
+    hipLaunchKernelGGL(qe_filter_kernel<true>, dim3(grid), dim3(VM_BLOCK_THREADS), 0, stream, args);
+  else
+    hipLaunchKernelGGL(qe_filter_kernel<false>, dim3(grid), dim3(VM_BLOCK_THREADS), 0, stream, args);
   return hipGetLastError();
 }
 
@@ -1169,15 +1424,11 @@ uint32_t aggregate_lds_slots(int n_accs, const DeviceInfo &dev) {
 hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStream_t stream) {
   if (args.n_rows <= 0) return hipSuccess;
   size_t lds = agg_lds_bytes(args.n_accs, args.lds_cap);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)qe_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       64 * 1024 + 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
   int grid = grid_for(args.n_rows, VM_BLOCK_ROWS, dev.cus * 2);
-  hipLaunchKernelGGL(qe_aggregate_kernel, dim3(grid), dim3(VM_BLOCK_THREADS), lds, stream, args);
+  if (program_needs_full(args.prog))
+    hipLaunchKernelGGL(qe_aggregate_kernel<true>, dim3(grid), dim3(VM_BLOCK_THREADS), lds, stream, args);
+  else
+    hipLaunchKernelGGL(qe_aggregate_kernel<false>, dim3(grid), dim3(VM_BLOCK_THREADS), lds, stream, args);
   return hipGetLastError();
 }
 

@@ -23,6 +23,7 @@ constexpr int VM_MAX_DEPTH = 4;
 constexpr int VM_MAX_OUTS = 12;
 constexpr int VM_MAX_KEYS = 4;
 constexpr int VM_MAX_ACCS = 16;
+constexpr int VM_NCACHE = 6;          // columns whose loads are issued together at the start of a wave-step
 
 // Filter tiles: 4 steps of 1024 rows = 4096 rows per ticket.
 constexpr int FILTER_STEPS = 4;
@@ -51,6 +52,8 @@ enum VmOp : uint32_t {
   OP_UTF8_EQ_LIT, OP_UTF8_NE_LIT,  // arg = col | lit<<8 (lits[lit] = device ptr, lits[lit+1] = length)
   OP_UTF8_EQ_COL, OP_UTF8_NE_COL,  // arg = colA | colB<<8
   OP_I64_TO_F64,                   // top slot: int64 -> float64 (AVG over integers)
+  // pushes out of the per-step column cache (arg = cache slot)
+  OP_PUSH_CACHED64, OP_PUSH_CACHED32, OP_PUSH_CACHEDBOOL,
   OP_COUNT_
 };
 
@@ -66,10 +69,19 @@ struct VmCol {
   uint64_t reserved;
 };
 
+// Kind of a cached column's raw bits.
+enum VmCacheKind : uint8_t { CK_64 = 0, CK_32 = 1, CK_BOOL = 2 };
+
 struct VmProgram {
   VmCol cols[VM_MAX_COLS];
   uint64_t lits[VM_MAX_LITS];
   uint32_t insn[VM_MAX_INSN];
+  // The first `cache_n` distinct fixed-width columns a program touches are loaded into
+  // registers up front, all loads in flight together, instead of one round trip per use.
+  uint8_t cache_col[8];   // program column of each cache slot
+  uint8_t cache_kind[8];  // VmCacheKind
+  uint32_t cache_n;
+  uint32_t cache_pad;
 };
 
 struct VmOut {
@@ -102,6 +114,8 @@ struct FilterArgs {
   VmOut outs[VM_MAX_OUTS];
   int32_t n_outs;
   uint32_t pred_pc;
+  uint32_t pred_cache_mask;  // cache slots the predicate reads
+  uint32_t out_cache_mask;   // cache slots the output expressions read
   int64_t n_rows;
   int64_t n_tiles;
   FilterScratch *scratch;
@@ -146,15 +160,33 @@ struct AggTable {
 
 constexpr unsigned long long AGG_EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
 
+// The aggregate kernel runs one list of tasks per wave-step, so that the expression
+// interpreter is instantiated once in the kernel (instruction-cache footprint).
+enum AggRole : uint8_t {
+  ROLE_PRED = 1,    // evaluate, AND into the active rows
+  ROLE_KEY = 2,     // evaluate, pack into the 64-bit key (idx = key field)
+  ROLE_LOOKUP = 3,  // no expression: find / claim the group slot of every active row
+  ROLE_ACC = 4      // evaluate (if has_eval), fold into accumulator idx
+};
+struct VmTask {
+  uint32_t pc;
+  uint8_t role;
+  uint8_t idx;
+  uint8_t has_eval;
+  uint8_t pad;
+};
+constexpr int VM_MAX_TASKS = 2 + VM_MAX_KEYS + VM_MAX_ACCS;
+
 struct AggArgs {
   VmProgram prog;
   VmKey keys[VM_MAX_KEYS];
   VmAcc accs[VM_MAX_ACCS];
+  VmTask tasks[VM_MAX_TASKS];
   AggTable table;
   int32_t n_keys;
   int32_t n_accs;
-  int32_t has_pred;
-  uint32_t pred_pc;
+  int32_t n_tasks;
+  int32_t pad0;
   int64_t n_rows;
   uint32_t lds_cap;    // LDS table slots (power of two)
   uint32_t lds_limit;  // stop claiming LDS slots past this many

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Small single-GPU driver for profiling one configuration under rocprofv3.
+
+usage: probe.py <c2|c3|c5|c4> [rows] [reps]
+"""
+import importlib
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+qe = importlib.import_module("query-engine_amd")
+
+
+def main():
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "c5"
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 64_000_000
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    ctx = qe.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    k = torch.empty(n, dtype=torch.int64, device=dev)
+    a = torch.empty(n, dtype=torch.float64, device=dev)
+    b = torch.empty(n, dtype=torch.float64, device=dev)
+    c = torch.empty(n, dtype=torch.float64, device=dev)
+    if cfg == "c4":
+        ctx.generate(2, 77, 0, n, 1_000_000, 1.1, k.data_ptr())
+    else:
+        ctx.generate(3, 43, 0, n, 0, 0, k.data_ptr())
+    ctx.generate(0, 44, 0, n, -1.0, 1.0, a.data_ptr())
+    ctx.generate(0, 45, 0, n, -1.0, 1.0, b.data_ptr())
+    ctx.generate(0, 46, 0, n, 0.0, 1.0, c.data_ptr())
+    ctx.synchronize()
+    C = qe.ColumnExpression
+    batch = qe.Batch.from_torch(ctx, [k, a, b, c])
+
+    def plan():
+        scan = qe.ScanExec(ctx, [batch])
+        if cfg == "c2":
+            sel = qe.SelectionExec([scan], qe.GtExpression(C(3), qe.LiteralFloatExpression(0.5)))
+            return qe.ProjectionExec([sel], [qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
+        if cfg == "c3":
+            return qe.AggregateExec([scan], [C(0)], [qe.SumExpression(C(3)), qe.CountExpression(None)], group_capacity_hint=64)
+        if cfg == "c4":
+            return qe.AggregateExec([scan], [C(0)], [qe.SumExpression(C(3)), qe.MinExpression(C(3)), qe.MaxExpression(C(3)),
+                                                      qe.AvgExpression(C(3))], group_capacity_hint=1_100_000)
+        if cfg == "p":
+            return qe.ProjectionExec([scan], [qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
+        sel = qe.SelectionExec([scan], qe.GtExpression(C(3), qe.LiteralFloatExpression(0.5)))
+        proj = qe.ProjectionExec([sel], [C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
+        return qe.AggregateExec([proj], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None)], group_capacity_hint=64)
+
+    out = list(plan().execute())[0]
+    torch.cuda.synchronize()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = list(plan().execute())[0]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    print(cfg, "rows", n, "ms", dt * 1e3, "Grows/s", n / dt / 1e9, "out_rows", out.num_rows, ctx.profile_read())
+
+
+if __name__ == "__main__":
+    main()
