@@ -97,7 +97,11 @@ enum {
   /* Reproduce physical_expressions.rs:264-268: for Sub/Div/Mod with a scalar
    * left operand and an array right operand the reference computes
    * `array OP scalar`.  On by default (drop-in parity). */
-  QE_FLAG_REFERENCE_SCALAR_ARRAY_SWAP = 1
+  QE_FLAG_REFERENCE_SCALAR_ARRAY_SWAP = 1,
+  /* Always run the general interpreter kernels, never a kernel that was built
+   * ahead of time for the exact shape of a launch.  Results are the same
+   * either way; the flag exists for testing and for timing the two paths. */
+  QE_FLAG_NO_SPECIALIZED_KERNELS = 2
 };
 
 typedef struct qe_context qe_context;
@@ -244,6 +248,19 @@ qe_status qe_generate_column(qe_context *ctx, int32_t kind, uint64_t seed, int64
  * with HIP events on the context's stream (enabled by qe_context_profile). */
 qe_status qe_context_profile(qe_context *ctx, int32_t enable);
 qe_status qe_context_profile_read(qe_context *ctx, char *buf, int64_t buf_len, int64_t *needed);
+
+/* Introspection (no counterpart in the reference; needs no GPU): lowers
+ *   Scan(schema) -> [Selection predicate] -> [Projection exprs] -> [Aggregate group_exprs, agg_exprs]
+ * exactly as qe_plan_execute would and writes a JSON description of every
+ * kernel launch (interpreter code, column-cache layout, sink descriptors and
+ * the launch signature that selects a shape-specialised kernel) to `buf`.
+ * Expressions are borrowed, not consumed.  The build uses it to generate the
+ * shape-specialised kernels; it is also the way to see what a plan compiles to. */
+qe_status qe_lowering_describe(const int32_t *col_types, const uint8_t *col_nullable, int32_t n_cols, uint32_t flags,
+                               const qe_expr *predicate, const qe_expr *const *exprs, int32_t n_exprs,
+                               const qe_expr *const *group_exprs, int32_t n_group_exprs,
+                               const qe_agg_expr *const *agg_exprs, int32_t n_agg_exprs, int32_t mode,
+                               char *buf, int64_t buf_len, int64_t *needed);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,7 @@ OP_EQ, OP_NEQ, OP_GT, OP_GTEQ, OP_LT, OP_LTEQ, OP_AND, OP_OR, OP_ADD, OP_SUB, OP
 AGG_MAX, AGG_MIN, AGG_SUM, AGG_COUNT, AGG_AVG = 1, 2, 3, 4, 5
 AGG_MODE_SINGLE, AGG_MODE_PARTIAL, AGG_MODE_FINAL = 0, 1, 2
 FLAG_REFERENCE_SCALAR_ARRAY_SWAP = 1
+FLAG_NO_SPECIALIZED_KERNELS = 2
 
 _NP_OF_TYPE = {TYPE_INT32: np.int32, TYPE_INT64: np.int64, TYPE_FLOAT64: np.float64}
 _TYPE_OF_NP = {np.dtype(np.int32): TYPE_INT32, np.dtype(np.int64): TYPE_INT64, np.dtype(np.float64): TYPE_FLOAT64,
@@ -94,6 +95,10 @@ ABI = {
                                        C.c_void_p]),
     "qe_context_profile": (C.c_int32, [C.c_void_p, C.c_int32]),
     "qe_context_profile_read": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "qe_lowering_describe": (C.c_int32, [C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_int32, C.c_uint32, C.c_void_p,
+                                         C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
+                                         C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_char_p, C.c_int64,
+                                         C.POINTER(C.c_int64)]),
 }
 
 
@@ -737,3 +742,31 @@ def final_plan(scan_of_partials, n_group_exprs, agg_exprs, group_capacity_hint=0
     groups = [ColumnExpression(i) for i in range(n_group_exprs)]
     aggs = [type(a)(ColumnExpression(first[i])) for i, a in enumerate(agg_exprs)]
     return AggregateExec(scan_of_partials, groups, aggs, mode=AGG_MODE_FINAL, group_capacity_hint=group_capacity_hint)
+
+
+def describe_lowering(col_types, col_nullable=None, predicate=None, exprs=(), group_exprs=(), agg_exprs=(),
+                      mode=AGG_MODE_SINGLE, flags=FLAG_REFERENCE_SCALAR_ARRAY_SWAP):
+    """What Scan(schema) -> [Selection] -> [Projection] -> [Aggregate] compiles to: a dict with one entry per
+    kernel launch (interpreter code, cache layout, sink descriptors, launch signature).  Needs no GPU."""
+    import json
+    n = len(col_types)
+    types = (C.c_int32 * max(1, n))(*col_types)
+    nullable = (C.c_uint8 * max(1, n))(*[1 if x else 0 for x in (col_nullable or [False] * n)])
+    pred = predicate._build() if predicate is not None else None
+    es, gs, ags = _build_list(exprs), _build_list(group_exprs), [a._build() for a in agg_exprs]
+    try:
+        earr = (C.c_void_p * max(1, len(es)))(*es)
+        garr = (C.c_void_p * max(1, len(gs)))(*gs)
+        aarr = (C.c_void_p * max(1, len(ags)))(*ags)
+        buf = C.create_string_buffer(1 << 16)
+        need = C.c_int64()
+        _check(lib.qe_lowering_describe(types, nullable, n, flags, pred, earr, len(es), garr, len(gs), aarr, len(ags), mode,
+                                        buf, len(buf), C.byref(need)))
+        return json.loads(buf.value.decode())
+    finally:
+        if pred is not None:
+            lib.qe_expr_free(pred)
+        for h in es + gs:
+            lib.qe_expr_free(h)
+        for h in ags:
+            lib.qe_agg_expr_free(h)

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libqe_gpu.so")
-SOURCES = ["qe_kernels.hip", "qe_core.cpp", "qe_exec.cpp"]
+SOURCES = ["qe_kernels.hip", "qe_static.hip", "qe_core.cpp", "qe_exec.cpp"]
 # -ffp-contract=off: `a + b*c` must round twice like the reference's separate mul and add passes.
 # -munsafe-fp-atomics: native ds_add_f64 / global_atomic_add_f64 instead of compare-swap loops.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",

@@ -71,8 +71,9 @@ void Context::prof_begin(const char *name) {
   QE_HIP(hipEventRecord(r.start, stream));
   launches.push_back(r);
 }
-void Context::prof_end() {
+void Context::prof_end(const char *actual_name) {
   if (!profiling || launches.empty()) return;
+  if (actual_name) launches.back().name = actual_name;
   QE_HIP(hipEventRecord(launches.back().stop, stream));
 }
 
@@ -560,6 +561,7 @@ void Compiler::emit(const ExprPtr &e, int depth) {
     if (col->kind != EK_COLUMN || litv->kind != EK_LITERAL)
       fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression `" + expr_to_string(e) + "` is not supported.");
     if (!litv->valid) fail(QE_ERR_SCALAR_TO_ARRAY, "Couldn't convert Scalar value `null` to array.");
+    if (!ctx) fail(QE_ERR_INVALID_ARGUMENT, "a utf8 literal needs a device context");
     BufferPtr buf = device_buffer(ctx, litv->sval.size() + 1);
     QE_HIP(hipMemcpyAsync(buf->ptr, litv->sval.data(), litv->sval.size(), hipMemcpyHostToDevice, ctx->stream));
     keepalive.push_back(buf);

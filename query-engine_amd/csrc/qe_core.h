@@ -49,7 +49,7 @@ struct Context : std::enable_shared_from_this<Context> {
   void bind() const;
   void sync() const;
   void prof_begin(const char *name);
-  void prof_end();
+  void prof_end(const char *actual_name = nullptr);  // the kernel variant the launcher picked
   ~Context();
 };
 

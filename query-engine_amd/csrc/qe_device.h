@@ -1,0 +1,1007 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels of the physical-plan hot path:
+//   * qe_project_kernel   — fused expression evaluation (ProjectionIterator::next,
+//                           physical_plan/mod.rs:138-156 in the reference)
+//   * qe_filter_kernel    — predicate -> stable compaction -> projection
+//                           (SelectionIterator::next + filter_chunk, physical_plan/mod.rs:205-229)
+//   * qe_aggregate_kernel — predicate/projection fused into a hash aggregate with a per-workgroup
+//                           LDS table and a global open-addressing table
+//                           (AggregateExec::execute, physical_plan/mod.rs:292-374)
+//   * qe_finalize_kernel  — group table -> output batch (physical_plan/mod.rs:375-488)
+// All of them are HBM-bandwidth bound byte/integer/f64 streaming work: wide coalesced loads,
+// wave64 ballot/popcount ranking, LDS scans and LDS atomics; there is no dense contraction here.
+//
+// Code size is a first-order cost for the interpreter kernels: the instruction cache holds
+// 64 KiB and a wave that jumps around a larger body stalls on instruction fetch.  Hence every
+// kernel instantiates the interpreter ONCE, rare operations share one out-of-line-style copy
+// that works on temporaries, and per-row work that is more than a few instructions long runs in
+// a rolled loop that rotates the four row registers instead of being unrolled four times.
+#pragma once
+#include "qe_kernels.h"
+
+namespace qe {
+
+// ------------------------------------------------------------------ helpers
+// Column value buffers are 16-byte aligned (the host re-aligns imported buffers that are not),
+// so a lane's row pair is one global_load_dwordx4 / global_store_dwordx4.  A pair that starts on
+// a valid row never leaves the 16-byte granule of that row, so it cannot cross into an unmapped
+// page even when the second row is past the end of the column.
+struct alignas(16) U64x2 { uint64_t x, y; };
+struct alignas(8) U32x2 { uint32_t x, y; };
+
+struct Slot {
+  uint64_t v[VM_R];
+  uint32_t valid;  // bit j: row j holds a non-null value
+};
+
+// Rows of one wave-step.  Lane l, slot j  <->  row0 + (j>>1)*128 + 2*l + (j&1):
+// every 16-byte load of an 8-byte column is contiguous across the 64 lanes.
+struct RowCtx {
+  int64_t row0;
+  int64_t n;
+  uint32_t lane;
+  uint32_t active;  // bit j: row j takes part
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__device__ __forceinline__ uint32_t in_range_bits(int64_t row0, uint32_t lane, int64_t n) {
+  uint32_t a = 0;
+  int64_t r = row0 + 2 * (int64_t)lane;
+  if (r < n) a |= 1u;
+  if (r + 1 < n) a |= 2u;
+  if (r + 128 < n) a |= 4u;
+  if (r + 129 < n) a |= 8u;
+  return a;
+}
+
+// Hides a lane-varying value from loop-invariant code motion: without it everything the
+// interpreter might derive from loop-invariant registers (addresses from the lane id, decoded
+// forms of every cached column) is precomputed ahead of the instruction loop and kept live
+// across it, which costs far more registers than the work saved.
+__device__ __forceinline__ uint32_t opaque(uint32_t x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+__device__ __forceinline__ uint64_t opaque64(uint64_t x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+__device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
+__device__ __forceinline__ uint64_t d2u(double d) { return (uint64_t)__double_as_longlong(d); }
+
+__device__ __forceinline__ uint32_t rot4(uint32_t m) { return ((m >> 1) | (m << 3)) & 0xFu; }
+#define QE_ROT4(a)   \
+  {                  \
+    auto t_ = (a)[0]; \
+    (a)[0] = (a)[1]; \
+    (a)[1] = (a)[2]; \
+    (a)[2] = (a)[3]; \
+    (a)[3] = t_;     \
+  }
+
+// Two adjacent bits (rows 2l, 2l+1 of each chunk) out of an LSB-first bitmap.
+__device__ __forceinline__ uint32_t load_bits4(const uint8_t *bm, const RowCtx &c) {
+  uint32_t out = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    uint32_t a2 = (c.active >> (2 * h)) & 3u;
+    if (a2) {
+      int64_t r = c.row0 + h * 128 + 2 * (int64_t)c.lane;
+      uint32_t byte = bm[r >> 3];
+      out |= ((byte >> (r & 7)) & 3u) << (2 * h);
+    }
+  }
+  return out;
+}
+
+__device__ __forceinline__ bool utf8_equal(const uint8_t *a, const uint8_t *b, int32_t len) {
+  for (int32_t i = 0; i < len; ++i)
+    if (a[i] != b[i]) return false;
+  return true;
+}
+
+// ------------------------------------------------------- per-step column cache
+// Raw bits of up to VM_NCACHE columns for the 4 rows of the lane.  Filled by cache_load with
+// every load in flight at once; only ever indexed with compile-time constants.
+struct ColCache {
+  uint64_t v[VM_NCACHE][VM_R];
+  uint32_t valid[VM_NCACHE];  // validity bits (4 per lane), 0xF when the column has no bitmap
+};
+
+__device__ __forceinline__ void cache_load_one(const VmProgram &P, int i, const RowCtx &c, uint64_t (&v)[VM_R],
+                                               uint32_t &valid) {
+  const VmCol &col = P.cols[P.cache_col[i]];
+  const uint32_t kind = P.cache_kind[i];
+  // every path produces the four words in locals and the cache entry is written once, below:
+  // storing from inside the branches makes the compiler merge them into one store with a
+  // computed index, which pushes the whole cache out to scratch memory
+  uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+  const int64_t r0 = c.row0 + 2 * (int64_t)c.lane;
+  const int64_t r1 = r0 + 128;
+  const bool a0 = (c.active & 3u) != 0, a1 = (c.active & 12u) != 0;
+  if (kind == CK_64) {
+    const uint64_t *p = (const uint64_t *)col.values;
+    if (a0) {
+      U64x2 t = *(const U64x2 *)(p + r0);
+      w0 = t.x;
+      w1 = t.y;
+    }
+    if (a1) {
+      U64x2 t = *(const U64x2 *)(p + r1);
+      w2 = t.x;
+      w3 = t.y;
+    }
+  } else if (kind == CK_32) {
+    const uint32_t *p = (const uint32_t *)col.values;  // raw pairs; sign-extended when pushed
+    if (a0) {
+      U32x2 t = *(const U32x2 *)(p + r0);
+      w0 = (uint64_t)t.x | ((uint64_t)t.y << 32);
+    }
+    if (a1) {
+      U32x2 t = *(const U32x2 *)(p + r1);
+      w1 = (uint64_t)t.x | ((uint64_t)t.y << 32);
+    }
+  } else {
+    w0 = load_bits4((const uint8_t *)col.values, c);
+  }
+  uint32_t vb = 0xFu;
+  if (col.validity) vb = load_bits4(col.validity, c);
+  v[0] = w0;
+  v[1] = w1;
+  v[2] = w2;
+  v[3] = w3;
+  valid = vb;
+}
+
+template <int I>
+__device__ __forceinline__ void cache_load_from(const VmProgram &P, uint32_t mask, const RowCtx &c, ColCache &K) {
+  if constexpr (I < VM_NCACHE) {
+    if ((mask >> I) & 1u) cache_load_one(P, I, c, K.v[I], K.valid[I]);
+    cache_load_from<I + 1>(P, mask, c, K);
+  }
+}
+__device__ __forceinline__ void cache_load(const VmProgram &P, uint32_t mask, const RowCtx &c, ColCache &K) {
+  cache_load_from<0>(P, mask, c, K);
+}
+
+// ------------------------------------------------------------ the VM proper
+// The program (instruction words, literals) is wave-uniform data that the interpreter reads at a
+// run-time index.  Reading it from the kernel-argument segment costs one scalar-memory round
+// trip per fetch, in a dependent chain; instead lane i of a few VGPRs holds word i, loaded once
+// per kernel, and a fetch is a v_readlane_b32.
+struct ProgRegs {
+  uint32_t code0, code1;    // insn[lane], insn[64 + lane]
+  uint32_t lit_lo, lit_hi;  // lits[lane & 31]
+};
+static_assert(VM_MAX_INSN == 128 && VM_MAX_LITS <= 64, "ProgRegs layout");
+
+__device__ __forceinline__ ProgRegs prog_regs(const VmProgram &P, uint32_t lane) {
+  ProgRegs R;
+  R.code0 = P.insn[lane];
+  R.code1 = P.insn[64 + lane];
+  uint64_t l = P.lits[lane & (VM_MAX_LITS - 1)];
+  R.lit_lo = (uint32_t)l;
+  R.lit_hi = (uint32_t)(l >> 32);
+  return R;
+}
+__device__ __forceinline__ uint32_t fetch_insn(const ProgRegs &R, uint32_t pc) {
+  return pc < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)R.code0, (int)pc)
+                 : (uint32_t)__builtin_amdgcn_readlane((int)R.code1, (int)(pc - 64));
+}
+__device__ __forceinline__ uint64_t fetch_lit(const ProgRegs &R, uint32_t i) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)R.lit_lo, (int)i);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)R.lit_hi, (int)i);
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// Selecting a stack slot / cache entry by a run-time (wave-uniform) number.  Each case passes
+// its values through `opaque`: otherwise the optimiser folds the cases into one access with a
+// computed index, and an array indexed that way is placed in scratch memory instead of registers.
+__device__ __forceinline__ void slot_copy(Slot &r, const Slot &s) {
+  // element by element: a whole-struct copy is a memcpy to the optimiser and leaves the
+  // slots in scratch memory
+  r.v[0] = opaque64(s.v[0]);
+  r.v[1] = opaque64(s.v[1]);
+  r.v[2] = opaque64(s.v[2]);
+  r.v[3] = opaque64(s.v[3]);
+  r.valid = opaque(s.valid);
+}
+__device__ __forceinline__ void slot_get(const Slot (&S)[VM_MAX_DEPTH], uint32_t i, Slot &out) {
+  switch (i) {
+    case 0: slot_copy(out, S[0]); break;
+    case 1: slot_copy(out, S[1]); break;
+    case 2: slot_copy(out, S[2]); break;
+    default: slot_copy(out, S[3]); break;
+  }
+}
+__device__ __forceinline__ void slot_put(Slot (&S)[VM_MAX_DEPTH], uint32_t i, const Slot &x) {
+  switch (i) {
+    case 0: slot_copy(S[0], x); break;
+    case 1: slot_copy(S[1], x); break;
+    case 2: slot_copy(S[2], x); break;
+    default: slot_copy(S[3], x); break;
+  }
+}
+
+__device__ __forceinline__ void cached_raw(const ColCache &K, uint32_t slot, uint64_t (&v)[VM_R], uint32_t &valid) {
+#define QE_TAKE(i)                                                               \
+  {                                                                              \
+    _Pragma("unroll") for (int j = 0; j < VM_R; ++j) v[j] = opaque64(K.v[i][j]); \
+    valid = opaque(K.valid[i]);                                                  \
+  }
+  switch (slot) {
+    case 0: QE_TAKE(0) break;
+    case 1: QE_TAKE(1) break;
+    case 2: QE_TAKE(2) break;
+    case 3: QE_TAKE(3) break;
+    case 4: QE_TAKE(4) break;
+    default: QE_TAKE(5) break;
+  }
+#undef QE_TAKE
+}
+
+// Hot pushes, instantiated per stack depth: a cached column or a literal.
+__device__ __forceinline__ void vm_push_fast(uint32_t op, uint32_t arg, const ProgRegs &R, const ColCache &K, Slot &s) {
+  if (op == OP_PUSH_LIT) {
+    uint64_t l = fetch_lit(R, arg);
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) s.v[j] = l;
+    s.valid = 0xFu;
+    return;
+  }
+  cached_raw(K, arg, s.v, s.valid);
+  if (op == OP_PUSH_CACHED32) {
+    // raw int32 pairs -> sign-extended values.  `opaque`: decoded here, per instruction; left
+    // visible, the decoded form of every cache slot is precomputed ahead of the instruction loop
+    uint32_t w0 = opaque((uint32_t)s.v[0]), w1 = opaque((uint32_t)(s.v[0] >> 32));
+    uint32_t w2 = opaque((uint32_t)s.v[1]), w3 = opaque((uint32_t)(s.v[1] >> 32));
+    s.v[0] = (uint64_t)(int64_t)(int32_t)w0;
+    s.v[1] = (uint64_t)(int64_t)(int32_t)w1;
+    s.v[2] = (uint64_t)(int64_t)(int32_t)w2;
+    s.v[3] = (uint64_t)(int64_t)(int32_t)w3;
+  } else if (op == OP_PUSH_CACHEDBOOL) {
+    uint32_t bits = opaque((uint32_t)s.v[0]);
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) s.v[j] = (bits >> j) & 1u;
+  }
+}
+
+#define QE_BIN_EACH(expr)                            \
+  _Pragma("unroll") for (int j = 0; j < VM_R; ++j) { \
+    uint64_t x = a.v[j], y = b.v[j];                 \
+    (void)x;                                         \
+    (void)y;                                         \
+    a.v[j] = (expr);                                 \
+  }
+
+// Hot binaries, instantiated per stack depth: a = a OP b.  Result validity = AND of the
+// operands (arrow2 binary kernels combine validity bitmaps the same way).
+__device__ __forceinline__ void vm_binary_fast(uint32_t op, Slot &a, const Slot &b) {
+  switch (op) {
+    case OP_ADD_I32: QE_BIN_EACH((uint64_t)(int64_t)(int32_t)((uint32_t)x + (uint32_t)y)); break;
+    case OP_SUB_I32: QE_BIN_EACH((uint64_t)(int64_t)(int32_t)((uint32_t)x - (uint32_t)y)); break;
+    case OP_MUL_I32: QE_BIN_EACH((uint64_t)(int64_t)(int32_t)((uint32_t)x * (uint32_t)y)); break;
+    case OP_ADD_I64: QE_BIN_EACH(x + y); break;
+    case OP_SUB_I64: QE_BIN_EACH(x - y); break;
+    case OP_MUL_I64: QE_BIN_EACH(x * y); break;
+    case OP_ADD_F64: QE_BIN_EACH(d2u(u2d(x) + u2d(y))); break;
+    case OP_SUB_F64: QE_BIN_EACH(d2u(u2d(x) - u2d(y))); break;
+    case OP_MUL_F64: QE_BIN_EACH(d2u(u2d(x) * u2d(y))); break;
+    case OP_EQ_I64: QE_BIN_EACH((uint64_t)(x == y)); break;
+    case OP_NE_I64: QE_BIN_EACH((uint64_t)(x != y)); break;
+    case OP_LT_I64: QE_BIN_EACH((uint64_t)((int64_t)x < (int64_t)y)); break;
+    case OP_LE_I64: QE_BIN_EACH((uint64_t)((int64_t)x <= (int64_t)y)); break;
+    case OP_GT_I64: QE_BIN_EACH((uint64_t)((int64_t)x > (int64_t)y)); break;
+    case OP_GE_I64: QE_BIN_EACH((uint64_t)((int64_t)x >= (int64_t)y)); break;
+    case OP_EQ_F64: QE_BIN_EACH((uint64_t)(u2d(x) == u2d(y))); break;
+    case OP_NE_F64: QE_BIN_EACH((uint64_t)(u2d(x) != u2d(y))); break;
+    case OP_LT_F64: QE_BIN_EACH((uint64_t)(u2d(x) < u2d(y))); break;
+    case OP_LE_F64: QE_BIN_EACH((uint64_t)(u2d(x) <= u2d(y))); break;
+    case OP_GT_F64: QE_BIN_EACH((uint64_t)(u2d(x) > u2d(y))); break;
+    case OP_GE_F64: QE_BIN_EACH((uint64_t)(u2d(x) >= u2d(y))); break;
+    case OP_AND: QE_BIN_EACH(x & y); break;
+    default: QE_BIN_EACH(x | y); break;  // OP_OR
+  }
+  a.valid &= b.valid;
+}
+
+__host__ __device__ constexpr bool op_is_fast_push(uint32_t op) { return op >= OP_PUSH_CACHED64 || op == OP_PUSH_LIT; }
+__host__ __device__ constexpr bool op_is_fast_binary(uint32_t op) {
+  return (op >= OP_ADD_I32 && op <= OP_MUL_I32) || (op >= OP_ADD_I64 && op <= OP_MUL_I64) ||
+         (op >= OP_ADD_F64 && op <= OP_MUL_F64) || (op >= OP_EQ_I64 && op <= OP_OR);
+}
+
+// Everything else: one copy for all stack depths.  Operands are copied into the temporaries
+// a / b, the result goes back through slot_put.  `d` is the stack depth before the instruction.
+__device__ __forceinline__ void vm_slow(uint32_t op, uint32_t d, uint32_t arg, const VmProgram &P, const RowCtx &c0,
+                                        const ColCache &K, Slot (&S)[VM_MAX_DEPTH]) {
+  RowCtx c;
+  c.row0 = c0.row0;
+  c.n = c0.n;
+  c.active = c0.active;
+  c.lane = opaque(c0.lane);
+  const bool is_push = (op <= OP_PUSH_ROWID) || (op >= OP_UTF8_EQ_LIT && op <= OP_UTF8_NE_COL);
+  const bool is_unary = op == OP_I64_TO_F64;
+  Slot a, b;
+  uint32_t dst;
+  if (is_push) {
+    dst = d;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) a.v[j] = 0, b.v[j] = 0;
+    a.valid = b.valid = 0xFu;
+  } else if (is_unary) {
+    dst = d - 1;
+    slot_get(S, d - 1, a);
+    slot_copy(b, a);
+  } else {
+    dst = d - 2;
+    slot_get(S, d - 2, a);
+    slot_get(S, d - 1, b);
+  }
+  switch (op) {
+    case OP_PUSH_COL64:
+    case OP_PUSH_COL32: {
+      // columns beyond the cache: one round trip per use
+      const VmCol &col = P.cols[arg];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool on = ((c.active >> (2 * h)) & 3u) != 0;
+        const int64_t r = c.row0 + h * 128 + 2 * (int64_t)c.lane;
+        uint64_t x = 0, y = 0;
+        if (on) {
+          if (op == OP_PUSH_COL64) {
+            U64x2 t = *(const U64x2 *)((const uint64_t *)col.values + r);
+            x = t.x;
+            y = t.y;
+          } else {
+            U32x2 t = *(const U32x2 *)((const uint32_t *)col.values + r);
+            x = (uint64_t)(int64_t)(int32_t)t.x;
+            y = (uint64_t)(int64_t)(int32_t)t.y;
+          }
+        }
+        a.v[2 * h] = x;
+        a.v[2 * h + 1] = y;
+      }
+      a.valid = col.validity ? load_bits4(col.validity, c) : 0xFu;
+      break;
+    }
+    case OP_PUSH_COLBOOL: {
+      const VmCol &col = P.cols[arg];
+      uint32_t bits = load_bits4((const uint8_t *)col.values, c);
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) a.v[j] = (bits >> j) & 1u;
+      a.valid = col.validity ? load_bits4(col.validity, c) : 0xFu;
+      break;
+    }
+    case OP_PUSH_ROWID: {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) a.v[j] = (uint64_t)(c.row0 + (j >> 1) * 128 + 2 * (int64_t)c.lane + (j & 1));
+      break;
+    }
+    case OP_UTF8_EQ_LIT:
+    case OP_UTF8_NE_LIT:
+    case OP_UTF8_EQ_COL:
+    case OP_UTF8_NE_COL: {
+      const bool vs_lit = op == OP_UTF8_EQ_LIT || op == OP_UTF8_NE_LIT;
+      const bool want_eq = op == OP_UTF8_EQ_LIT || op == OP_UTF8_EQ_COL;
+      const VmCol &ca = P.cols[arg & 0xffu];
+      const uint32_t second = (arg >> 8) & 0xffu;
+      const uint8_t *lit = vs_lit ? (const uint8_t *)P.lits[second] : nullptr;
+      const int32_t llen = vs_lit ? (int32_t)P.lits[second + 1] : 0;
+      const VmCol &cb = P.cols[vs_lit ? 0 : second];
+      uint32_t act = c.active;
+      // rolled over the four rows: row j = (it>>1)*128 + (it&1) ahead of the lane's first row
+#pragma unroll 1
+      for (int it = 0; it < VM_R; ++it) {
+        uint64_t res = 0;
+        if (act & 1u) {
+          int64_t r = c.row0 + (it >> 1) * 128 + 2 * (int64_t)c.lane + (it & 1);
+          int32_t a0 = ca.offsets[r], a1 = ca.offsets[r + 1];
+          bool eq;
+          if (vs_lit) {
+            eq = (a1 - a0 == llen) && utf8_equal((const uint8_t *)ca.values + a0, lit, llen);
+          } else {
+            int32_t b0 = cb.offsets[r], b1 = cb.offsets[r + 1];
+            eq = (a1 - a0 == b1 - b0) && utf8_equal((const uint8_t *)ca.values + a0, (const uint8_t *)cb.values + b0, a1 - a0);
+          }
+          res = (eq == want_eq) ? 1u : 0u;
+        }
+        a.v[0] = res;
+        QE_ROT4(a.v);
+        act = rot4(act);
+      }
+      uint32_t va = ca.validity ? load_bits4(ca.validity, c) : 0xFu;
+      uint32_t vb = (!vs_lit && cb.validity) ? load_bits4(cb.validity, c) : 0xFu;
+      a.valid = va & vb;
+      break;
+    }
+    case OP_SWAP: {
+      slot_put(S, d - 1, a);
+      slot_copy(a, b);
+      break;
+    }
+    case OP_I64_TO_F64: {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) a.v[j] = d2u((double)(int64_t)a.v[j]);
+      break;
+    }
+    case OP_DIV_F64: {
+#pragma unroll 1
+      for (int it = 0; it < VM_R; ++it) {
+        a.v[0] = d2u(u2d(a.v[0]) / u2d(b.v[0]));
+        QE_ROT4(a.v);
+        QE_ROT4(b.v);
+      }
+      a.valid &= b.valid;
+      break;
+    }
+    case OP_DIV_I32:
+    case OP_MOD_I32:
+    case OP_DIV_I64:
+    case OP_MOD_I64: {
+      // int32 operands are sign-extended, so one 64-bit division serves both widths; only the
+      // overflow case (MIN / -1) depends on the width.  x/0, x%0 and MIN/-1 panic in the
+      // reference; here they give null.
+      const bool w32 = op == OP_DIV_I32 || op == OP_MOD_I32;
+      const bool want_mod = op == OP_MOD_I32 || op == OP_MOD_I64;
+      const int64_t tmin = w32 ? (int64_t)INT32_MIN : INT64_MIN;
+      uint32_t valid = a.valid & b.valid;
+#pragma unroll 1
+      for (int it = 0; it < VM_R; ++it) {
+        int64_t x = (int64_t)a.v[0], y = (int64_t)b.v[0];
+        int64_t r = 0;
+        if (y == 0 || (x == tmin && y == -1)) {
+          valid &= ~1u;
+        } else {
+          int64_t q = x / y;
+          r = want_mod ? x - q * y : q;
+        }
+        a.v[0] = (uint64_t)r;
+        QE_ROT4(a.v);
+        QE_ROT4(b.v);
+        valid = rot4(valid);
+      }
+      a.valid = valid;
+      break;
+    }
+    default:
+      break;
+  }
+  slot_put(S, dst, a);
+}
+
+// Runs the postfix code starting at `pc` until OP_END; the value is left in S[0].
+// Control flow depends only on the (wave-uniform) instruction words.  FULL = false leaves out
+// vm_slow (division, utf8, uncached columns, casts): the host picks that variant when a program
+// has none of those, and it needs far fewer registers.
+template <bool FULL>
+__device__ __forceinline__ void vm_eval(const VmProgram &P, const ProgRegs &R, uint32_t pc, const RowCtx &c,
+                                        const ColCache &K, Slot (&S)[VM_MAX_DEPTH]) {
+  for (;;) {
+    uint32_t ins = fetch_insn(R, pc++);
+    uint32_t op = ins & 0xffu;
+    if (op == OP_END) break;
+    uint32_t d = (ins >> 8) & 0xfu;
+    uint32_t arg = ins >> 12;
+    if (op_is_fast_binary(op)) {
+      switch (d) {
+        case 2: vm_binary_fast(op, S[0], S[1]); break;
+        case 3: vm_binary_fast(op, S[1], S[2]); break;
+        default: vm_binary_fast(op, S[2], S[3]); break;
+      }
+    } else if (op_is_fast_push(op)) {
+      switch (d) {
+        case 0: vm_push_fast(op, arg, R, K, S[0]); break;
+        case 1: vm_push_fast(op, arg, R, K, S[1]); break;
+        case 2: vm_push_fast(op, arg, R, K, S[2]); break;
+        default: vm_push_fast(op, arg, R, K, S[3]); break;
+      }
+    } else if constexpr (FULL) {
+      vm_slow(op, d, arg, P, c, K, S);
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t bool_bits(const Slot &s) {
+  uint32_t b = 0;
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) b |= ((uint32_t)s.v[j] & 1u) << j;
+  return b;
+}
+
+// ------------------------------------------------------------ dense stores
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {
+  x &= 0xffffu;
+  x = (x | (x << 8)) & 0x00ff00ffu;
+  x = (x | (x << 4)) & 0x0f0f0f0fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x;
+}
+
+// Writes the 256 bits of a wave-step (bit j of `bits4` = row j of the lane) as 8 dwords.
+__device__ __forceinline__ void store_bitmap256(uint32_t *words, const RowCtx &c, uint32_t bits4) {
+  uint64_t b0 = __ballot((bits4 & 1u) != 0), b1 = __ballot((bits4 & 2u) != 0);
+  uint64_t b2 = __ballot((bits4 & 4u) != 0), b3 = __ballot((bits4 & 8u) != 0);
+  if (c.lane < 8) {
+    uint32_t h = c.lane >> 2, q = c.lane & 3u;
+    uint64_t ev = h ? b2 : b0, od = h ? b3 : b1;
+    uint32_t w = spread16((uint32_t)(ev >> (16 * q))) | (spread16((uint32_t)(od >> (16 * q))) << 1);
+    int64_t idx = (c.row0 >> 5) + c.lane;
+    if ((idx << 5) < c.n) words[idx] = w;
+  }
+}
+
+// Output buffers are allocated by the library with slack, so a row pair is always one store.
+__device__ __forceinline__ void store_dense(const VmOut &o, const RowCtx &c, const Slot &s) {
+  uint32_t inr = in_range_bits(c.row0, c.lane, c.n);
+  if (o.type == VT_BOOL) {
+    store_bitmap256((uint32_t *)o.values, c, bool_bits(s) & inr);
+  } else if (o.type == VT_I32) {
+    uint32_t *p = (uint32_t *)o.values;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int64_t r = c.row0 + h * 128 + 2 * (int64_t)c.lane;
+      if (r < c.n) {
+        U32x2 t;
+        t.x = (uint32_t)s.v[2 * h];
+        t.y = (uint32_t)s.v[2 * h + 1];
+        *(U32x2 *)(p + r) = t;
+      }
+    }
+  } else {
+    uint64_t *p = (uint64_t *)o.values;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int64_t r = c.row0 + h * 128 + 2 * (int64_t)c.lane;
+      if (r < c.n) {
+        U64x2 t;
+        t.x = s.v[2 * h];
+        t.y = s.v[2 * h + 1];
+        *(U64x2 *)(p + r) = t;
+      }
+    }
+  }
+  if (o.validity) store_bitmap256(o.validity, c, s.valid & inr);
+}
+
+// ------------------------------------------------------------ filter kernel
+constexpr unsigned long long ST_FLAG_AGG = 1ull << 62;
+constexpr unsigned long long ST_FLAG_PREFIX = 2ull << 62;
+constexpr unsigned long long ST_VALUE_MASK = (1ull << 62) - 1;
+constexpr int LOOKBACK_SPIN_LIMIT = 1 << 22;
+static_assert(FILTER_STEPS == 4, "the filter kernel selects among four per-step prefixes");
+
+__device__ __forceinline__ unsigned long long ld_status(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_status(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Decoupled look-back over the per-tile status words, run by one full wave.
+// Each status word is a single 8-byte {flag, value} granule written by one
+// agent-scope store, so no further ordering between tiles is needed.  Tiles are
+// handed out by a ticket counter, so every predecessor of a running tile is
+// itself running or finished: the wait below always ends.
+__device__ unsigned long long lookback_exclusive(unsigned long long *status, int64_t tile, unsigned long long total,
+                                                 uint32_t lane, unsigned long long *err) {
+  if (tile == 0) {
+    if (lane == 0) st_status(&status[0], ST_FLAG_PREFIX | total);
+    return 0;
+  }
+  if (lane == 0) st_status(&status[tile], ST_FLAG_AGG | total);
+  unsigned long long excl = 0;
+  int64_t idx = tile - 1;
+  int spins = 0;
+  for (;;) {
+    int64_t t = idx - (int64_t)lane;
+    unsigned long long v = (t >= 0) ? ld_status(&status[t]) : ST_FLAG_PREFIX;
+    uint32_t flag = (uint32_t)(v >> 62);
+    uint64_t inv = __ballot(flag == 0u);
+    uint64_t pre = __ballot(flag == 2u);
+    if (pre != 0) {
+      int p = __builtin_ctzll(pre);
+      uint64_t need = (p == 63) ? ~0ull : ((1ull << (p + 1)) - 1ull);
+      if ((inv & need) == 0) {
+        unsigned long long contrib = ((int)lane <= p) ? (v & ST_VALUE_MASK) : 0ull;
+        excl += wave_sum_u64(contrib);
+        break;
+      }
+    } else if (inv == 0) {
+      excl += wave_sum_u64(v & ST_VALUE_MASK);
+      idx -= 64;
+      continue;
+    }
+    if (++spins > LOOKBACK_SPIN_LIMIT) {
+      if (lane == 0) *err = 1ull;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  if (lane == 0) st_status(&status[tile], ST_FLAG_PREFIX | ((excl + total) & ST_VALUE_MASK));
+  return excl;
+}
+
+__device__ __forceinline__ uint32_t popc_sel(uint32_t sel) {
+  return (uint32_t)(__popcll(__ballot((sel & 1u) != 0)) + __popcll(__ballot((sel & 2u) != 0)) +
+                    __popcll(__ballot((sel & 4u) != 0)) + __popcll(__ballot((sel & 8u) != 0)));
+}
+
+// Output position (relative to the wave-step's base) of each selected row, in row order.
+__device__ __forceinline__ void rank_rows(uint32_t sel, uint32_t (&rank)[VM_R]) {
+  uint64_t b0 = __ballot((sel & 1u) != 0), b1 = __ballot((sel & 2u) != 0);
+  uint64_t b2 = __ballot((sel & 4u) != 0), b3 = __ballot((sel & 8u) != 0);
+  uint32_t c0 = (uint32_t)(__popcll(b0) + __popcll(b1));
+  uint32_t lt0 = mbcnt64(b0) + mbcnt64(b1);
+  uint32_t lt1 = mbcnt64(b2) + mbcnt64(b3);
+  rank[0] = lt0;
+  rank[1] = lt0 + (sel & 1u);
+  rank[2] = c0 + lt1;
+  rank[3] = c0 + lt1 + ((sel >> 2) & 1u);
+}
+
+__device__ __forceinline__ void store_compact(const VmOut &o, unsigned long long base, uint32_t sel,
+                                              const uint32_t (&rank)[VM_R], const Slot &s) {
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    if ((sel >> j) & 1u) {
+      unsigned long long pos = base + rank[j];
+      if (o.type == VT_BOOL) {
+        if (s.v[j] & 1u) atomicOr((uint32_t *)o.values + (pos >> 5), 1u << (pos & 31u));
+      } else if (o.type == VT_I32) {
+        ((uint32_t *)o.values)[pos] = (uint32_t)s.v[j];
+      } else {
+        ((uint64_t *)o.values)[pos] = s.v[j];
+      }
+      if (o.validity && ((s.valid >> j) & 1u)) atomicOr(o.validity + (pos >> 5), 1u << (pos & 31u));
+    }
+  }
+}
+
+// --------------------------------------------------------- aggregate kernel
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return x;
+}
+
+// Order-preserving unsigned image: min/max of the images = image of the min/max.
+// float64: -0.0 < +0.0 and NaN never reaches here (NaN inputs are skipped).
+__device__ __forceinline__ uint64_t ord_image(uint64_t bits, uint32_t type) {
+  if (type == VT_F64) return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
+  return bits ^ 0x8000000000000000ull;
+}
+__device__ __forceinline__ uint64_t ord_inverse(uint64_t img, uint32_t type) {
+  if (type == VT_F64) return (img >> 63) ? (img & 0x7fffffffffffffffull) : ~img;
+  return img ^ 0x8000000000000000ull;
+}
+
+__device__ __forceinline__ uint64_t acc_identity(uint32_t op) { return op == ACC_MIN ? ~0ull : 0ull; }
+
+constexpr int32_t SLOT_NONE = INT32_MIN;
+constexpr int LDS_MAX_PROBE = 8;
+
+struct LdsTable {
+  unsigned long long *keys;  // [cap + 1]
+  unsigned long long *acc;   // [n_accs][cap + 1]
+  uint32_t *rowcnt;          // [cap + 1]
+  uint32_t *nn;              // [n_accs][cap + 1]
+  uint32_t *used;            // claimed slots
+  uint32_t cap;
+  uint32_t stride;           // cap + 1
+  uint32_t limit;
+};
+
+__device__ __forceinline__ int64_t global_find_or_claim(const AggTable &T, uint64_t key, uint64_t h) {
+  if (key == AGG_EMPTY_KEY) {
+    // the one key that collides with the empty marker lives in the reserved slot
+    unsigned long long old = atomicCAS(&T.keys[T.cap], AGG_EMPTY_KEY, 0ull);
+    if (old == AGG_EMPTY_KEY) atomicAdd(&T.ctrl[0], 1ull);
+    return (int64_t)T.cap;
+  }
+  uint64_t mask = T.cap - 1;
+  uint64_t s = (h >> 20) & mask;
+  for (uint64_t p = 0; p <= mask; ++p) {
+    unsigned long long cur = __hip_atomic_load(&T.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == key) return (int64_t)s;
+    if (cur == AGG_EMPTY_KEY) {
+      unsigned long long old = atomicCAS(&T.keys[s], AGG_EMPTY_KEY, (unsigned long long)key);
+      if (old == AGG_EMPTY_KEY) {
+        atomicAdd(&T.ctrl[0], 1ull);
+        return (int64_t)s;
+      }
+      if (old == key) return (int64_t)s;
+    }
+    s = (s + 1) & mask;
+  }
+  atomicExch(&T.ctrl[1], 1ull);
+  return -1;
+}
+
+// Cheap 32-bit hash for the LDS table (the global table uses the full mix64).
+__device__ __forceinline__ uint32_t hash32(uint64_t key) {
+  uint32_t h = (uint32_t)key * 0x9E3779B1u ^ (uint32_t)(key >> 32) * 0x85EBCA77u;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 13;
+  return h;
+}
+
+// LDS slot of `key` (claiming one if new), or -1 when the key does not fit the LDS table.
+__device__ __forceinline__ int32_t lds_find_or_claim(const LdsTable &L, uint64_t key) {
+  if (key == AGG_EMPTY_KEY) {
+    (void)atomicCAS(&L.keys[L.cap], AGG_EMPTY_KEY, 0ull);
+    return (int32_t)L.cap;
+  }
+  uint32_t s = hash32(key) & (L.cap - 1);
+  for (int p = 0; p < LDS_MAX_PROBE; ++p) {
+    unsigned long long cur = *(volatile unsigned long long *)&L.keys[s];
+    if (cur == key) return (int32_t)s;
+    if (cur == AGG_EMPTY_KEY) {
+      if (*(volatile uint32_t *)L.used >= L.limit) break;
+      unsigned long long old = atomicCAS(&L.keys[s], AGG_EMPTY_KEY, (unsigned long long)key);
+      if (old == AGG_EMPTY_KEY) {
+        atomicAdd(L.used, 1u);
+        return (int32_t)s;
+      }
+      if (old == key) return (int32_t)s;
+    }
+    s = (s + 1) & (L.cap - 1);
+  }
+  return -1;
+}
+
+__device__ __forceinline__ void acc_apply(unsigned long long *p, uint32_t op, uint64_t v) {
+  switch (op) {
+    case ACC_SUM_F64: atomicAdd((double *)p, u2d(v)); break;
+    case ACC_MIN: atomicMin(p, (unsigned long long)v); break;
+    case ACC_MAX: atomicMax(p, (unsigned long long)v); break;
+    default: atomicAdd(p, (unsigned long long)v); break;  // ACC_SUM_I64, ACC_COUNT
+  }
+}
+
+__device__ __forceinline__ uint64_t acc_combine(uint32_t op, uint64_t a, uint64_t b) {
+  switch (op) {
+    case ACC_SUM_F64: return d2u(u2d(a) + u2d(b));
+    case ACC_MIN: return a < b ? a : b;
+    case ACC_MAX: return a > b ? a : b;
+    default: return a + b;
+  }
+}
+
+__device__ __forceinline__ uint64_t wave_reduce_acc(uint32_t op, uint64_t v) {
+#pragma unroll 1
+  for (int o = 32; o > 0; o >>= 1) v = acc_combine(op, v, (uint64_t)__shfl_xor((unsigned long long)v, o));
+  return v;
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
+  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, lane);
+  uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), lane);
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+constexpr uint32_t LEADER_MIN_ROWS = 24;
+constexpr int LEADER_TRIES = 2;
+constexpr int32_t SLOT_LDS_MISS = -1;  // transient: the row still needs a global slot
+
+// ------------------------------------------------------------ aggregate sink
+// Shared by the interpreted and the statically specialised aggregate kernels.
+__device__ __forceinline__ void agg_lds_setup(LdsTable &L, unsigned long long *lds_raw, uint32_t lds_cap, uint32_t lds_limit,
+                                              int n_accs) {
+  L.cap = lds_cap;
+  L.stride = lds_cap + 1;
+  L.limit = lds_limit;
+  L.keys = lds_raw;
+  L.acc = L.keys + L.stride;
+  L.rowcnt = (uint32_t *)(L.acc + (size_t)n_accs * L.stride);
+  L.nn = L.rowcnt + L.stride;
+  L.used = L.nn + (size_t)n_accs * L.stride;
+}
+
+struct AggRows {
+  uint64_t key[VM_R];
+  int32_t slot[VM_R];  // >= 0 LDS slot; <= -2: global slot g as -2 - g; SLOT_NONE: dropped
+  uint32_t rem;        // rows folded one by one
+  uint32_t lead_mb;    // rows folded through the wave reduction
+  int32_t lead_slot;   // wave-uniform; SLOT_NONE = no dominant key in this wave-step
+};
+
+// Finds / claims the group slot of every active row and counts the rows in.
+__device__ __forceinline__ void agg_lookup(const LdsTable &L, const AggTable &T, uint32_t active, uint32_t lane, AggRows &G) {
+  uint32_t rem = active;
+  // ---- a key that dominates the wave-step?  Try the first row of up to two lanes.
+  uint64_t ball = __ballot(rem != 0);
+  uint64_t k0 = 0;
+  uint32_t lead_cnt = 0, lead_mb = 0;
+  int src = 0;
+#pragma unroll 1
+  for (int tr = 0; tr < LEADER_TRIES && ball != 0; ++tr) {
+    src = __builtin_ctzll(ball);
+    // `opaque64`: a plain select chain is folded into one load with a computed index, which
+    // moves the key registers to scratch memory
+    uint64_t kl = opaque64(G.key[3]);
+    if (rem & 4u) kl = opaque64(G.key[2]);
+    if (rem & 2u) kl = opaque64(G.key[1]);
+    if (rem & 1u) kl = opaque64(G.key[0]);
+    k0 = readlane64(kl, src);
+    uint32_t mb = 0;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j)
+      if (((rem >> j) & 1u) && G.key[j] == k0) mb |= 1u << j;
+    const uint32_t cnt = popc_sel(mb);
+    if (cnt >= LEADER_MIN_ROWS) {
+      lead_mb = mb;
+      lead_cnt = cnt;
+      break;
+    }
+    ball &= ~__ballot(mb != 0);  // next candidate: a lane none of whose rows matched
+  }
+  rem &= ~lead_mb;
+  // ---- LDS slots: the dominant key (one lane) and the remaining rows, back to back
+  int32_t lsl = SLOT_NONE;
+  if (lead_cnt != 0 && (int)lane == src) lsl = lds_find_or_claim(L, k0);
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    G.slot[j] = SLOT_NONE;
+    if ((rem >> j) & 1u) G.slot[j] = lds_find_or_claim(L, G.key[j]);
+  }
+  // ---- keys the LDS table has no room for go to the global table (rare: rolled loop)
+  uint32_t miss = 0;
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j)
+    if (G.slot[j] == SLOT_LDS_MISS) miss |= 1u << j;
+  const bool lead_miss = lsl == SLOT_LDS_MISS;
+  if (__ballot(miss != 0 || lead_miss) != 0) {
+#pragma unroll 1
+    for (int it = 0; it <= VM_R; ++it) {
+      const bool lead_it = it == 0;
+      const bool act = lead_it ? lead_miss : ((miss & 1u) != 0);
+      const uint64_t kcur = lead_it ? k0 : G.key[0];
+      int32_t sl = lead_it ? lsl : G.slot[0];
+      if (act) {
+        int64_t g = global_find_or_claim(T, kcur, mix64(kcur));
+        sl = g < 0 ? SLOT_NONE : (int32_t)(-2 - (int32_t)g);
+      }
+      if (lead_it) {
+        lsl = sl;
+      } else {
+        G.slot[0] = sl;
+        miss = rot4(miss);
+        QE_ROT4(G.key);
+        QE_ROT4(G.slot);
+      }
+    }
+  }
+  // ---- row counts
+  if (lead_cnt != 0 && (int)lane == src && lsl != SLOT_NONE) {
+    if (lsl >= 0)
+      atomicAdd(&L.rowcnt[lsl], lead_cnt);
+    else
+      atomicAdd(&T.rowcnt[(uint32_t)(-2 - lsl)], (unsigned long long)lead_cnt);
+  }
+  G.lead_slot = lead_cnt != 0 ? __builtin_amdgcn_readlane(lsl, src) : SLOT_NONE;
+  G.lead_mb = G.lead_slot == SLOT_NONE ? 0u : lead_mb;
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    if ((rem >> j) & 1u) {
+      if (G.slot[j] >= 0)
+        atomicAdd(&L.rowcnt[G.slot[j]], 1u);
+      else if (G.slot[j] != SLOT_NONE)
+        atomicAdd(&T.rowcnt[(uint32_t)(-2 - G.slot[j])], 1ull);
+      else
+        rem &= ~(1u << j);  // the global table is full: the host grows it and runs again
+    }
+  }
+  G.rem = rem;
+}
+
+// Folds one evaluated input (values + validity of the 4 rows) into accumulator `idx`.
+__device__ __forceinline__ void agg_fold(const LdsTable &L, const AggTable &T, uint32_t idx, uint32_t op, uint32_t in_type,
+                                         bool track, const Slot &in, const AggRows &G, uint32_t lane) {
+  uint32_t valid = in.valid;
+  uint64_t v[VM_R];
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    uint64_t x = in.v[j];
+    if (op == ACC_MIN || op == ACC_MAX) {
+      if (in_type == VT_F64 && u2d(x) != u2d(x)) valid &= ~(1u << j);  // NaN is ignored by min / max
+      x = ord_image(x, in_type);
+    } else if (op == ACC_COUNT) {
+      x = 1;
+    }
+    v[j] = x;
+  }
+  unsigned long long *lacc = L.acc + idx * L.stride;
+  unsigned long long *gacc = T.acc + (uint64_t)idx * T.stride;
+  // wave-reduced contribution of the dominant key
+  if (G.lead_slot != SLOT_NONE) {
+    const uint32_t m = G.lead_mb & valid;
+    uint64_t part = acc_identity(op);
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j)
+      if ((m >> j) & 1u) part = acc_combine(op, part, v[j]);
+    part = wave_reduce_acc(op, part);
+    const uint32_t part_cnt = popc_sel(m);
+    if (lane == 0 && part_cnt != 0) {
+      if (G.lead_slot >= 0) {
+        acc_apply(lacc + G.lead_slot, op, part);
+        if (track) atomicAdd(&L.nn[idx * L.stride + G.lead_slot], part_cnt);
+      } else {
+        const uint32_t g = (uint32_t)(-2 - G.lead_slot);
+        acc_apply(gacc + g, op, part);
+        if (track) atomicAdd(&T.nn[(uint64_t)idx * T.stride + g], (unsigned long long)part_cnt);
+      }
+    }
+  }
+  const uint32_t m = G.rem & valid;
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    if ((m >> j) & 1u) {
+      if (G.slot[j] >= 0) {
+        acc_apply(lacc + G.slot[j], op, v[j]);
+        if (track) atomicAdd(&L.nn[idx * L.stride + G.slot[j]], 1u);
+      } else {
+        const uint32_t g = (uint32_t)(-2 - G.slot[j]);
+        acc_apply(gacc + g, op, v[j]);
+        if (track) atomicAdd(&T.nn[(uint64_t)idx * T.stride + g], 1ull);
+      }
+    }
+  }
+}
+
+// Workgroup's LDS table -> global table, once, at the end of the kernel.
+__device__ __forceinline__ void agg_flush(const LdsTable &L, const AggTable &T, const VmAcc *accs, int n_accs) {
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < L.stride; i += blockDim.x) {
+    unsigned long long k = L.keys[i];
+    uint32_t rc = L.rowcnt[i];
+    if (i == L.cap) {
+      if (k == AGG_EMPTY_KEY) continue;  // reserved slot never claimed
+      k = AGG_EMPTY_KEY;
+    } else if (k == AGG_EMPTY_KEY) {
+      continue;
+    }
+    int64_t g = global_find_or_claim(T, k, mix64(k));
+    if (g < 0) continue;
+    if (rc) atomicAdd(&T.rowcnt[g], (unsigned long long)rc);
+    for (int a = 0; a < n_accs; ++a) {
+      uint32_t op = accs[a].op;
+      unsigned long long val = L.acc[a * L.stride + i];
+      if (val != acc_identity(op) || op == ACC_SUM_F64) acc_apply(&T.acc[(uint64_t)a * T.stride + g], op, val);
+      uint32_t nn = L.nn[a * L.stride + i];
+      if (nn) atomicAdd(&T.nn[(uint64_t)a * T.stride + g], (unsigned long long)nn);
+    }
+  }
+}
+
+__device__ __forceinline__ void agg_lds_clear(const LdsTable &L, const VmAcc *accs, int n_accs) {
+  for (uint32_t i = threadIdx.x; i < L.stride; i += blockDim.x) {
+    L.keys[i] = AGG_EMPTY_KEY;
+    L.rowcnt[i] = 0;
+    for (int a = 0; a < n_accs; ++a) {
+      L.acc[a * L.stride + i] = acc_identity(accs[a].op);
+      L.nn[a * L.stride + i] = 0;
+    }
+  }
+  if (threadIdx.x == 0) *L.used = 0;
+  __syncthreads();
+}
+
+}  // namespace qe

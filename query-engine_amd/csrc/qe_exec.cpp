@@ -8,9 +8,11 @@
 // one batch (:274-283).
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <sstream>
 
 #include "qe_core.h"
+#include "qe_signature.h"
 
 namespace qe {
 
@@ -147,6 +149,62 @@ static Column utf8_gather_column(Context *ctx, const Column &src, const int64_t 
   return c;
 }
 
+// ---------------------------------------------------------------- lowering
+// Expression trees -> kernel arguments, apart from output buffers: those come from `sink`, so
+// that the same code serves execution (buffers from the pool) and qe_lowering_describe (none).
+using OutSink = std::function<void(int index, bool nullable, VmOut &o)>;
+
+// One projection launch for outs[vm_list[k...]]; returns the position after the last one placed.
+static size_t lower_project(Compiler &comp, const Schema &schema, const std::vector<ExprPtr> &outs, const std::vector<int> &types,
+                            const std::vector<int> &vm_list, size_t k, int64_t n, ProjectArgs &args, const OutSink &sink) {
+  int cnt = 0;
+  while (k < vm_list.size() && cnt < VM_MAX_OUTS && (cnt == 0 || comp.fits(outs[vm_list[k]]))) {
+    int i = vm_list[k];
+    VmOut &o = args.outs[cnt];
+    o.pc = comp.add(outs[i]);
+    o.type = vm_type_of(types[i]);
+    sink(i, expr_nullable(outs[i], schema), o);
+    ++cnt;
+    ++k;
+  }
+  args.prog = comp.prog;
+  args.n_outs = cnt;
+  args.n_rows = n;
+  return k;
+}
+
+// One filter launch: the predicate, optionally the row-id output (utf8 gathers), then as many
+// of outs[vm_list[k...]] as fit.
+static size_t lower_filter(Compiler &comp, const Schema &schema, const ExprPtr &pred, const std::vector<ExprPtr> &outs,
+                           const std::vector<int> &types, const std::vector<int> &vm_list, size_t k, int64_t n, void *rowid_values,
+                           FilterArgs &args, const OutSink &sink) {
+  args.pred_pc = comp.add(pred);
+  args.pred_cache_mask = comp.last_cache_mask;
+  int cnt = 0;
+  if (rowid_values) {
+    VmOut &o = args.outs[cnt++];
+    o.pc = comp.add_rowid();
+    o.type = VT_I64;
+    o.values = rowid_values;
+    o.validity = nullptr;
+  }
+  while (k < vm_list.size() && cnt < VM_MAX_OUTS && comp.fits(outs[vm_list[k]])) {
+    int i = vm_list[k];
+    VmOut &o = args.outs[cnt];
+    o.pc = comp.add(outs[i]);
+    args.out_cache_mask |= comp.last_cache_mask;
+    o.type = vm_type_of(types[i]);
+    sink(i, expr_nullable(outs[i], schema), o);
+    ++cnt;
+    ++k;
+  }
+  args.prog = comp.prog;
+  args.n_outs = cnt;
+  args.n_rows = n;
+  args.n_tiles = filter_num_tiles(n);
+  return k;
+}
+
 // Evaluates `outputs` (expressions over `in`'s columns) for the rows of `in`
 // that satisfy `pred` (all rows when null).  ProjectionIterator::next
 // (physical_plan/mod.rs:138-156) and SelectionIterator::next (:205-229) fused.
@@ -192,27 +250,17 @@ static Batch run_pipeline(Context *ctx, const Batch &in, const std::vector<ExprP
     while (k < vm_list.size()) {
       Compiler comp(ctx, &in);
       ProjectArgs args{};
-      int cnt = 0;
-      while (k < vm_list.size() && cnt < VM_MAX_OUTS && (cnt == 0 || comp.fits(outs[vm_list[k]]))) {
-        int i = vm_list[k];
-        bool nullable = expr_nullable(outs[i], schema);
+      k = lower_project(comp, schema, outs, types, vm_list, k, n, args, [&](int i, bool nullable, VmOut &o) {
         Column c = make_fixed_column(ctx, types[i], n, nullable, false);
         finish_fixed_column(c, n);
-        VmOut &o = args.outs[cnt];
-        o.pc = comp.add(outs[i]);
-        o.type = vm_type_of(types[i]);
         o.values = c.values->ptr;
         o.validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
         out.cols[i] = c;
-        ++cnt;
-        ++k;
-      }
-      args.prog = comp.prog;
-      args.n_outs = cnt;
-      args.n_rows = n;
-      ctx->prof_begin("qe_project_kernel");
-      QE_HIP(launch_project(args, ctx->dev, ctx->stream));
-      ctx->prof_end();
+      });
+      const char *kname = "qe_project_kernel";
+      ctx->prof_begin(kname);
+      QE_HIP(launch_project(args, ctx->dev, ctx->stream, &kname));
+      ctx->prof_end(kname);
       if (!comp.keepalive.empty()) ctx->sync();
     }
     return out;
@@ -241,41 +289,24 @@ static Batch run_pipeline(Context *ctx, const Batch &in, const std::vector<ExprP
   while (first || k < vm_list.size()) {
     Compiler comp(ctx, &in);
     FilterArgs args{};
-    args.pred_pc = comp.add(pred);
-    args.pred_cache_mask = comp.last_cache_mask;
-    int cnt = 0;
+    void *rowid_values = nullptr;
     if (first && need_rowid) {
       rowid = make_fixed_column(ctx, QE_TYPE_INT64, n, false, false);
-      VmOut &o = args.outs[cnt++];
-      o.pc = comp.add_rowid();
-      o.type = VT_I64;
-      o.values = rowid.values->ptr;
-      o.validity = nullptr;
+      rowid_values = rowid.values->ptr;
     }
-    while (k < vm_list.size() && cnt < VM_MAX_OUTS && comp.fits(outs[vm_list[k]])) {
-      int i = vm_list[k];
-      bool nullable = expr_nullable(outs[i], schema);
+    k = lower_filter(comp, schema, pred, outs, types, vm_list, k, n, rowid_values, args, [&](int i, bool nullable, VmOut &o) {
       Column c = make_fixed_column(ctx, types[i], n, nullable, false);
-      VmOut &o = args.outs[cnt];
-      o.pc = comp.add(outs[i]);
-      args.out_cache_mask |= comp.last_cache_mask;
-      o.type = vm_type_of(types[i]);
       o.values = c.values->ptr;
       o.validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
       out.cols[i] = c;
-      ++cnt;
-      ++k;
-    }
-    if (!first && cnt == 0) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression is too long for one kernel.");
-    args.prog = comp.prog;
-    args.n_outs = cnt;
-    args.n_rows = n;
-    args.n_tiles = filter_num_tiles(n);
+    });
+    if (!first && args.n_outs == 0) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression is too long for one kernel.");
     args.scratch = scratch;
     QE_HIP(launch_filter_reset(scratch, n, ctx->stream));
-    ctx->prof_begin("qe_filter_kernel");
-    QE_HIP(launch_filter(args, ctx->dev, ctx->stream));
-    ctx->prof_end();
+    const char *kname = "qe_filter_kernel";
+    ctx->prof_begin(kname);
+    QE_HIP(launch_filter(args, ctx->dev, ctx->stream, &kname));
+    ctx->prof_end(kname);
     if (first) {
       QE_HIP(hipMemcpyAsync(ctx->host_counters, scratch, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
       ctx->sync();
@@ -366,13 +397,13 @@ static ExprPtr make_to_f64(const ExprPtr &e) {
 
 static bool numeric(int t) { return t == QE_TYPE_INT32 || t == QE_TYPE_INT64 || t == QE_TYPE_FLOAT64; }
 
-static AggSpec build_agg_spec(Context *ctx, const Schema &schema, const std::vector<ExprPtr> &groups,
+static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::vector<ExprPtr> &groups,
                               const std::vector<AggExpr> &aggs, const std::vector<ExprPtr> &aggs_second, int mode) {
   AggSpec spec;
   int shift = 0;
   if ((int)groups.size() > VM_MAX_KEYS) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many group expressions.");
   for (size_t g = 0; g < groups.size(); ++g) {
-    ExprPtr e = expr_normalize(groups[g], ctx->flags);
+    ExprPtr e = expr_normalize(groups[g], flags);
     int t = expr_type(e, schema);
     int bits = t == QE_TYPE_INT32 ? 32 : t == QE_TYPE_INT64 ? 64 : t == QE_TYPE_BOOLEAN ? 1 : 0;
     // arrow2 cannot hash floats (the reference unwrap()s: physical_plan/mod.rs:317); utf8 keys are not lowered yet
@@ -392,7 +423,7 @@ static AggSpec build_agg_spec(Context *ctx, const Schema &schema, const std::vec
   }
   for (size_t i = 0; i < aggs.size(); ++i) {
     const AggExpr &ag = aggs[i];
-    ExprPtr e = ag.input ? expr_normalize(ag.input, ctx->flags) : nullptr;
+    ExprPtr e = ag.input ? expr_normalize(ag.input, flags) : nullptr;
     int t = e ? expr_type(e, schema) : 0;
     bool nullable = e ? expr_nullable(e, schema) : false;
     if (e && e->kind == EK_LITERAL && !e->valid) fail(QE_ERR_SCALAR_TO_ARRAY, "Couldn't convert Scalar value `null` to array.");
@@ -434,7 +465,7 @@ static AggSpec build_agg_spec(Context *ctx, const Schema &schema, const std::vec
       }
       case QE_AGG_AVG: {
         if (final_mode) {
-          ExprPtr cnt_e = aggs_second[i] ? expr_normalize(aggs_second[i], ctx->flags) : nullptr;
+          ExprPtr cnt_e = aggs_second[i] ? expr_normalize(aggs_second[i], flags) : nullptr;
           if (!e || t != QE_TYPE_FLOAT64 || !cnt_e || expr_type(cnt_e, schema) != QE_TYPE_INT64)
             fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "AVG partial columns must be (Float64 sum, Int64 count).");
           int a = add_acc(spec, ACC_SUM_F64, QE_TYPE_FLOAT64, false, e);
@@ -463,6 +494,34 @@ static AggSpec build_agg_spec(Context *ctx, const Schema &schema, const std::vec
     }
   }
   return spec;
+}
+
+// The aggregate kernel's task list: predicate, key fields, group lookup, one fold per accumulator.
+// `tracked` carries the validity tracking decided on the first batch of the scan.
+static void lower_aggregate(Compiler &comp, const Schema &schema, const ExprPtr &pred, const AggSpec &bspec, const AggSpec &tracked,
+                            AggArgs &args) {
+  int nt = 0;
+  if (pred) {
+    if (expr_type(pred, schema) != QE_TYPE_BOOLEAN)
+      fail(QE_ERR_NO_BOOLEAN_ARRAY_FOR_FILTER, "Expr doesn't evaluate to a boolean array, which is needed to filter.");
+    args.tasks[nt++] = VmTask{comp.add(pred), ROLE_PRED, 0, 1, 0};
+  }
+  for (size_t i = 0; i < bspec.keys.size(); ++i) {
+    args.keys[i] = bspec.keys[i];
+    args.keys[i].pc = comp.add(bspec.key_exprs[i]);
+    args.tasks[nt++] = VmTask{args.keys[i].pc, ROLE_KEY, (uint8_t)i, 1, 0};
+  }
+  args.tasks[nt++] = VmTask{0, ROLE_LOOKUP, 0, 0, 0};
+  for (size_t i = 0; i < bspec.accs.size(); ++i) {
+    args.accs[i] = bspec.accs[i].acc;
+    args.accs[i].track_nn = tracked.accs[i].acc.track_nn;
+    if (bspec.accs[i].input) args.accs[i].pc = comp.add(bspec.accs[i].input);
+    args.tasks[nt++] = VmTask{args.accs[i].pc, ROLE_ACC, (uint8_t)i, (uint8_t)(bspec.accs[i].input ? 1 : 0), 0};
+  }
+  args.n_tasks = nt;
+  args.prog = comp.prog;
+  args.n_keys = (int)bspec.keys.size();
+  args.n_accs = (int)bspec.accs.size();
 }
 
 struct AggIter : Iter {
@@ -508,7 +567,7 @@ struct AggIter : Iter {
           a2_second.push_back(second);
         }
         Schema schema = schema_of(in);
-        AggSpec bspec = build_agg_spec(ctx, schema, g2, a2, a2_second, mode);
+        AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode);
         if (!have_table) {
           spec = bspec;
           int na = (int)spec.accs.size();
@@ -542,36 +601,15 @@ struct AggIter : Iter {
         if (in.rows == 0) continue;
         Compiler comp(ctx, &in);
         AggArgs args{};
-        ExprPtr pred = s.pred ? expr_normalize(s.pred, ctx->flags) : nullptr;
-        int nt = 0;
-        if (pred) {
-          if (expr_type(pred, schema) != QE_TYPE_BOOLEAN)
-            fail(QE_ERR_NO_BOOLEAN_ARRAY_FOR_FILTER, "Expr doesn't evaluate to a boolean array, which is needed to filter.");
-          args.tasks[nt++] = VmTask{comp.add(pred), ROLE_PRED, 0, 1, 0};
-        }
-        for (size_t i = 0; i < bspec.keys.size(); ++i) {
-          args.keys[i] = bspec.keys[i];
-          args.keys[i].pc = comp.add(bspec.key_exprs[i]);
-          args.tasks[nt++] = VmTask{args.keys[i].pc, ROLE_KEY, (uint8_t)i, 1, 0};
-        }
-        args.tasks[nt++] = VmTask{0, ROLE_LOOKUP, 0, 0, 0};
-        for (size_t i = 0; i < bspec.accs.size(); ++i) {
-          args.accs[i] = bspec.accs[i].acc;
-          args.accs[i].track_nn = spec.accs[i].acc.track_nn;
-          if (bspec.accs[i].input) args.accs[i].pc = comp.add(bspec.accs[i].input);
-          args.tasks[nt++] = VmTask{args.accs[i].pc, ROLE_ACC, (uint8_t)i, (uint8_t)(bspec.accs[i].input ? 1 : 0), 0};
-        }
-        args.n_tasks = nt;
-        args.prog = comp.prog;
+        lower_aggregate(comp, schema, s.pred ? expr_normalize(s.pred, ctx->flags) : nullptr, bspec, spec, args);
         args.table = table;
-        args.n_keys = (int)bspec.keys.size();
-        args.n_accs = (int)bspec.accs.size();
         args.n_rows = in.rows;
         args.lds_cap = aggregate_lds_slots(args.n_accs, ctx->dev);
         args.lds_limit = args.lds_cap - args.lds_cap / 4;
-        ctx->prof_begin("qe_aggregate_kernel");
-        QE_HIP(launch_aggregate(args, ctx->dev, ctx->stream));
-        ctx->prof_end();
+        const char *kname = "qe_aggregate_kernel";
+        ctx->prof_begin(kname);
+        QE_HIP(launch_aggregate(args, ctx->dev, ctx->stream, &kname));
+        ctx->prof_end(kname);
         if (!comp.keepalive.empty()) ctx->sync();
       }
       // empty input: `iter.next().ok_or(Error::EmptyHashmapForAggregate)` (physical_plan/mod.rs:377)
@@ -713,6 +751,133 @@ static std::string plan_to_string(const Plan *p, int indent) {
   return o.str();
 }
 
+// ------------------------------------------------------- lowering description
+static void json_u32s(std::ostringstream &o, const char *key, const std::vector<uint32_t> &v) {
+  o << "\"" << key << "\":[";
+  for (size_t i = 0; i < v.size(); ++i) o << (i ? "," : "") << v[i];
+  o << "]";
+}
+
+static void describe_program(std::ostringstream &o, const VmProgram &P) {
+  int n = program_words_used(P);
+  json_u32s(o, "code", std::vector<uint32_t>(P.insn, P.insn + n));
+  o << ",";
+  json_u32s(o, "cache_kind", std::vector<uint32_t>(P.cache_kind, P.cache_kind + P.cache_n));
+}
+
+static void describe_outs(std::ostringstream &o, const VmOut *outs, int n) {
+  o << "\"outs\":[";
+  for (int i = 0; i < n; ++i)
+    o << (i ? "," : "") << "{\"pc\":" << outs[i].pc << ",\"type\":" << (int)outs[i].type << ",\"nullable\":" << (outs[i].validity ? 1 : 0) << "}";
+  o << "]";
+}
+
+// Lowers Scan(schema) -> [Selection pred] -> [Projection outs] -> [Aggregate groups, aggs] the way
+// execution does and renders every kernel launch it would make as JSON.  Touches no device.
+static std::string describe_lowering(const Schema &schema, uint32_t flags, const ExprPtr &pred_raw, const std::vector<ExprPtr> &outs_raw,
+                                     const std::vector<ExprPtr> &groups, const std::vector<AggExpr> &aggs, int mode) {
+  Batch in;
+  in.rows = 1 << 20;
+  for (size_t i = 0; i < schema.size(); ++i) {
+    Column c;
+    c.type = schema[i].type;
+    c.space = QE_MEM_DEVICE;
+    c.length = in.rows;
+    // placeholder addresses: nothing here is ever dereferenced
+    c.values = borrowed_buffer((const void *)(uintptr_t)(0x100000 * (3 * i + 1)), 0, QE_MEM_DEVICE);
+    if (schema[i].nullable) c.validity = borrowed_buffer((const void *)(uintptr_t)(0x100000 * (3 * i + 2)), 0, QE_MEM_DEVICE);
+    if (schema[i].type == QE_TYPE_UTF8) c.offsets = borrowed_buffer((const void *)(uintptr_t)(0x100000 * (3 * i + 3)), 0, QE_MEM_DEVICE);
+    in.cols.push_back(c);
+  }
+  OutSink sink = [](int, bool nullable, VmOut &o) {
+    o.values = (void *)(uintptr_t)0x10;
+    o.validity = nullable ? (uint32_t *)(uintptr_t)0x10 : nullptr;
+  };
+  std::ostringstream o;
+  o << "{\"launches\":[";
+  bool first_launch = true;
+  auto open_launch = [&](const char *kind, const std::vector<uint32_t> &sig) {
+    o << (first_launch ? "" : ",") << "{\"kind\":\"" << kind << "\",";
+    json_u32s(o, "sig", sig);
+    o << ",";
+    first_launch = false;
+  };
+  ExprPtr pred = pred_raw ? expr_normalize(pred_raw, flags) : nullptr;
+
+  if (!groups.empty() || !aggs.empty()) {
+    std::vector<ExprPtr> g2, second;
+    std::vector<AggExpr> a2;
+    for (auto &g : groups) g2.push_back(outs_raw.empty() ? g : expr_substitute(g, outs_raw));
+    for (auto &a : aggs) {
+      AggExpr x;
+      x.kind = a.kind;
+      x.input = a.input ? (outs_raw.empty() ? a.input : expr_substitute(a.input, outs_raw)) : nullptr;
+      a2.push_back(x);
+      ExprPtr sec;
+      if (mode == QE_AGG_MODE_FINAL && a.kind == QE_AGG_AVG && a.input && a.input->kind == EK_COLUMN) {
+        sec = make_column(a.input->index + 1);
+        if (!outs_raw.empty()) sec = expr_substitute(sec, outs_raw);
+      }
+      second.push_back(sec);
+    }
+    AggSpec spec = build_agg_spec(flags, schema, g2, a2, second, mode);
+    Compiler comp(nullptr, &in);
+    AggArgs args{};
+    lower_aggregate(comp, schema, pred, spec, spec, args);
+    open_launch("aggregate", signature(args));
+    describe_program(o, args.prog);
+    o << ",\"tasks\":[";
+    for (int i = 0; i < args.n_tasks; ++i)
+      o << (i ? "," : "") << "{\"pc\":" << args.tasks[i].pc << ",\"role\":" << (int)args.tasks[i].role << ",\"idx\":" << (int)args.tasks[i].idx
+        << ",\"eval\":" << (int)args.tasks[i].has_eval << "}";
+    o << "],\"keys\":[";
+    for (int i = 0; i < args.n_keys; ++i)
+      o << (i ? "," : "") << "{\"type\":" << (int)args.keys[i].type << ",\"shift\":" << (int)args.keys[i].shift << ",\"bits\":" << (int)args.keys[i].bits << "}";
+    o << "],\"accs\":[";
+    for (int i = 0; i < args.n_accs; ++i)
+      o << (i ? "," : "") << "{\"op\":" << (int)args.accs[i].op << ",\"type\":" << (int)args.accs[i].in_type << ",\"track\":" << (int)args.accs[i].track_nn
+        << ",\"has_input\":" << (int)args.accs[i].has_input << "}";
+    o << "]}";
+  } else {
+    std::vector<ExprPtr> outs;
+    for (auto &e : outs_raw) outs.push_back(expr_normalize(e, flags));
+    std::vector<int> types, vm_list;
+    for (auto &e : outs) types.push_back(expr_type(e, schema));
+    for (size_t i = 0; i < outs.size(); ++i) {
+      if (types[i] == QE_TYPE_UTF8) continue;                // gathered / broadcast by separate kernels
+      if (!pred && outs[i]->kind == EK_COLUMN) continue;     // shared with the input, no kernel
+      vm_list.push_back((int)i);
+    }
+    size_t k = 0;
+    bool first = true;
+    while ((pred && first) || k < vm_list.size()) {
+      Compiler comp(nullptr, &in);
+      if (pred) {
+        FilterArgs args{};
+        size_t k2 = lower_filter(comp, schema, pred, outs, types, vm_list, k, in.rows, nullptr, args, sink);
+        if (!first && k2 == k) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression is too long for one kernel.");
+        k = k2;
+        open_launch("filter", signature(args));
+        describe_program(o, args.prog);
+        o << ",";
+        describe_outs(o, args.outs, args.n_outs);
+        o << ",\"pred_pc\":" << args.pred_pc << ",\"pred_cache_mask\":" << args.pred_cache_mask << ",\"out_cache_mask\":" << args.out_cache_mask << "}";
+      } else {
+        ProjectArgs args{};
+        k = lower_project(comp, schema, outs, types, vm_list, k, in.rows, args, sink);
+        open_launch("project", signature(args));
+        describe_program(o, args.prog);
+        o << ",";
+        describe_outs(o, args.outs, args.n_outs);
+        o << "}";
+      }
+      first = false;
+    }
+  }
+  o << "]}";
+  return o.str();
+}
+
 }  // namespace qe
 
 // ==================================================================== C ABI
@@ -833,6 +998,7 @@ qe_status qe_context_set_flags(qe_context *ctx, uint32_t flags) {
   return guarded([&] {
     QE_REQUIRE(ctx, "ctx is null");
     ctx->c.flags = flags;
+    ctx->c.dev.specialised = !(flags & QE_FLAG_NO_SPECIALIZED_KERNELS);
   });
 }
 
@@ -1235,6 +1401,23 @@ qe_status qe_generate_column(qe_context *ctx, int32_t kind, uint64_t seed, int64
     ctx->c.prof_begin("qe_generate_kernel");
     QE_HIP(launch_generate(kind, seed, row0, n, lo, hi, device_out, ctx->c.stream));
     ctx->c.prof_end();
+  });
+}
+
+qe_status qe_lowering_describe(const int32_t *col_types, const uint8_t *col_nullable, int32_t n_cols, uint32_t flags,
+                               const qe_expr *predicate, const qe_expr *const *exprs, int32_t n_exprs,
+                               const qe_expr *const *group_exprs, int32_t n_group_exprs, const qe_agg_expr *const *agg_exprs,
+                               int32_t n_agg_exprs, int32_t mode, char *buf, int64_t buf_len, int64_t *needed) {
+  return guarded([&] {
+    QE_REQUIRE((col_types || n_cols == 0) && n_cols >= 0 && n_exprs >= 0 && n_group_exprs >= 0 && n_agg_exprs >= 0, "bad arguments");
+    Schema schema;
+    for (int i = 0; i < n_cols; ++i) schema.push_back(ColInfo{col_types[i], col_nullable ? col_nullable[i] != 0 : false});
+    std::vector<ExprPtr> outs, groups;
+    std::vector<AggExpr> aggs;
+    for (int i = 0; i < n_exprs; ++i) outs.push_back(exprs[i]->e);
+    for (int i = 0; i < n_group_exprs; ++i) groups.push_back(group_exprs[i]->e);
+    for (int i = 0; i < n_agg_exprs; ++i) aggs.push_back(agg_exprs[i]->a);
+    write_string(describe_lowering(schema, flags, predicate ? predicate->e : nullptr, outs, groups, aggs, mode), buf, buf_len, needed);
   });
 }
 

@@ -10,20 +10,22 @@ namespace qe {
 struct DeviceInfo {
   int cus;          // compute units
   int max_lds;      // bytes of LDS one workgroup may use
+  bool specialised = true;  // use a kernel built for the launch's exact shape when there is one
 };
 
 // Unfiltered projection: every expression of `args` evaluated for every row.
-hipError_t launch_project(const ProjectArgs &args, const DeviceInfo &dev, hipStream_t stream);
+// `kernel_name` (optional) receives the name of the kernel variant that was launched.
+hipError_t launch_project(const ProjectArgs &args, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name = nullptr);
 
 // Stable predicate -> compaction (+ projection).  `args.scratch` must hold
 // filter_scratch_bytes(n_rows) bytes, zeroed by launch_filter_reset before every launch.
 hipError_t launch_filter_reset(FilterScratch *scratch, int64_t n_rows, hipStream_t stream);
-hipError_t launch_filter(const FilterArgs &args, const DeviceInfo &dev, hipStream_t stream);
+hipError_t launch_filter(const FilterArgs &args, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name = nullptr);
 size_t filter_scratch_bytes(int64_t n_rows);
 int64_t filter_num_tiles(int64_t n_rows);
 
 // Hash aggregate update over one batch.
-hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStream_t stream);
+hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name = nullptr);
 // LDS bytes per slot for a given accumulator count, and the slot count chosen.
 uint32_t aggregate_lds_slots(int n_accs, const DeviceInfo &dev);
 
@@ -45,6 +47,15 @@ hipError_t launch_utf8_broadcast(const uint8_t *lit, int32_t len, int64_t n, int
 
 // Number of zero bits among the first n bits of a bitmap (null count).
 hipError_t launch_count_zero_bits(const uint32_t *bitmap, int64_t n, unsigned long long *out, hipStream_t stream);
+
+// Kernels built for one exact launch shape (qe_static.hip).  Each returns false when no such
+// kernel exists for `args`; otherwise it launches, sets *err and *kernel_name, and returns true.
+bool static_launch_project(const ProjectArgs &args, int grid, hipStream_t stream, hipError_t *err, const char **kernel_name);
+bool static_launch_filter(const FilterArgs &args, int grid, hipStream_t stream, hipError_t *err, const char **kernel_name);
+bool static_launch_aggregate(const AggArgs &args, int grid, size_t lds_bytes, hipStream_t stream, hipError_t *err,
+                             const char **kernel_name);
+int static_kernel_count();
+const char *static_kernel_name(int i);
 
 // Synthetic columns (see qe_generate_column in qe_gpu.h).
 hipError_t launch_generate(int kind, uint64_t seed, int64_t row0, int64_t n, double lo, double hi, void *out,

@@ -1,0 +1,263 @@
+// Kernels specialised at build time for one lowered launch shape ("Spec": interpreter code, cache
+// layout and sink descriptors fixed as compile-time constants; addresses, literal values and row
+// counts stay run-time arguments).  The interpreter loop, its dispatch and the stack-slot
+// selection all fold away: what is left is the straight-line code a hand-written kernel for
+// that one query would have.  The interpreted kernels in qe_kernels.hip serve every shape that
+// has no Spec; the results are identical by construction (same helpers, same evaluation order).
+#pragma once
+#include "qe_device.h"
+
+namespace qe {
+
+template <uint32_t KIND>
+__device__ __forceinline__ void cache_load_static(const VmCol &col, const RowCtx &c, uint64_t (&v)[VM_R], uint32_t &valid) {
+  const int64_t r0 = c.row0 + 2 * (int64_t)c.lane;
+  const int64_t r1 = r0 + 128;
+  const bool a0 = (c.active & 3u) != 0, a1 = (c.active & 12u) != 0;
+  v[0] = v[1] = v[2] = v[3] = 0;
+  if constexpr (KIND == CK_64) {
+    const uint64_t *p = (const uint64_t *)col.values;
+    if (a0) {
+      U64x2 t = *(const U64x2 *)(p + r0);
+      v[0] = t.x;
+      v[1] = t.y;
+    }
+    if (a1) {
+      U64x2 t = *(const U64x2 *)(p + r1);
+      v[2] = t.x;
+      v[3] = t.y;
+    }
+  } else if constexpr (KIND == CK_32) {
+    const uint32_t *p = (const uint32_t *)col.values;
+    if (a0) {
+      U32x2 t = *(const U32x2 *)(p + r0);
+      v[0] = (uint64_t)(int64_t)(int32_t)t.x;
+      v[1] = (uint64_t)(int64_t)(int32_t)t.y;
+    }
+    if (a1) {
+      U32x2 t = *(const U32x2 *)(p + r1);
+      v[2] = (uint64_t)(int64_t)(int32_t)t.x;
+      v[3] = (uint64_t)(int64_t)(int32_t)t.y;
+    }
+  } else {
+    uint32_t bits = load_bits4((const uint8_t *)col.values, c);
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) v[j] = (bits >> j) & 1u;
+  }
+  valid = 0xFu;  // a Spec only serves columns without a validity bitmap
+}
+
+// Loads the cache slots named by MASK (a compile-time constant), decoded, all loads in flight.
+template <class Spec, uint32_t MASK, int I>
+__device__ __forceinline__ void cache_fill_static(const VmProgram &P, const RowCtx &c, ColCache &K) {
+  if constexpr (I < Spec::cache_n) {
+    if constexpr ((MASK >> I) & 1u) cache_load_static<Spec::cache_kind[I]>(P.cols[P.cache_col[I]], c, K.v[I], K.valid[I]);
+    cache_fill_static<Spec, MASK, I + 1>(P, c, K);
+  }
+}
+
+template <class Spec, int PC>
+__device__ __forceinline__ void eval_static(const VmProgram &P, const ColCache &K, Slot (&S)[VM_MAX_DEPTH]) {
+  constexpr uint32_t ins = Spec::code[PC];
+  constexpr uint32_t op = ins & 0xffu, d = (ins >> 8) & 0xfu, arg = ins >> 12;
+  if constexpr (op != OP_END) {
+    if constexpr (op == OP_PUSH_LIT) {
+      const uint64_t l = P.lits[arg];
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) S[d].v[j] = l;
+      S[d].valid = 0xFu;
+    } else if constexpr (op >= OP_PUSH_CACHED64) {
+      // the cache already holds decoded values (cache_load_static)
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) S[d].v[j] = K.v[arg][j];
+      S[d].valid = K.valid[arg];
+    } else {
+      static_assert(op_is_fast_binary(op), "a Spec may only hold cached pushes, literals and the fast binaries");
+      vm_binary_fast(op, S[d - 2], S[d - 1]);
+    }
+    eval_static<Spec, PC + 1>(P, K, S);
+  }
+}
+
+// --------------------------------------------------------------- projection
+template <class Spec, int E>
+__device__ __forceinline__ void project_outs_static(const ProjectArgs &A, const RowCtx &c, const ColCache &K) {
+  if constexpr (E < Spec::n_outs) {
+    Slot S[VM_MAX_DEPTH];
+    eval_static<Spec, Spec::out_pc[E]>(A.prog, K, S);
+    VmOut o = A.outs[E];
+    o.type = (uint8_t)Spec::out_type[E];
+    o.validity = nullptr;
+    store_dense(o, c, S[0]);
+    project_outs_static<Spec, E + 1>(A, c, K);
+  }
+}
+
+template <class Spec>
+__global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_project_static(const ProjectArgs A) {
+  const uint32_t lane = lane_id();
+  const uint32_t wave = threadIdx.x >> 6;
+  const int64_t n = A.n_rows;
+  const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
+  for (int64_t ws = (int64_t)blockIdx.x * VM_BLOCK_WAVES + wave; ws < nsteps;
+       ws += (int64_t)gridDim.x * VM_BLOCK_WAVES) {
+    RowCtx c;
+    c.row0 = ws * VM_WAVE_ROWS;
+    c.n = n;
+    c.lane = lane;
+    c.active = in_range_bits(c.row0, lane, n);
+    ColCache K;
+    cache_fill_static<Spec, (1u << Spec::cache_n) - 1u, 0>(A.prog, c, K);
+    project_outs_static<Spec, 0>(A, c, K);
+  }
+}
+
+// ------------------------------------------------------------------- filter
+template <class Spec, int E>
+__device__ __forceinline__ void filter_outs_static(const FilterArgs &A, const ColCache &K, unsigned long long obase, uint32_t sel,
+                                                   const uint32_t (&rank)[VM_R]) {
+  if constexpr (E < Spec::n_outs) {
+    Slot S[VM_MAX_DEPTH];
+    eval_static<Spec, Spec::out_pc[E]>(A.prog, K, S);
+    VmOut o = A.outs[E];
+    o.type = (uint8_t)Spec::out_type[E];
+    o.validity = nullptr;
+    store_compact(o, obase, sel, rank, S[0]);
+    filter_outs_static<Spec, E + 1>(A, K, obase, sel, rank);
+  }
+}
+
+// Same tile / ticket / look-back protocol as qe_filter_kernel, with both phases specialised.
+template <class Spec>
+__global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_filter_static(const FilterArgs A) {
+  __shared__ unsigned long long s_tile;
+  __shared__ unsigned long long s_base;
+  __shared__ uint32_t s_cnt[FILTER_STEPS * VM_BLOCK_WAVES];
+  const uint32_t lane = lane_id();
+  const uint32_t wave = threadIdx.x >> 6;
+  const int64_t n = A.n_rows;
+  unsigned long long *status = (unsigned long long *)(A.scratch + 1);
+
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(&A.scratch->ticket, 1ull);
+    __syncthreads();
+    const int64_t tile = (int64_t)s_tile;
+    if (tile >= A.n_tiles) break;
+    const int64_t tile_row0 = tile * FILTER_TILE_ROWS;
+
+    uint32_t mask = 0;
+#pragma unroll
+    for (int s = 0; s < FILTER_STEPS; ++s) {
+      RowCtx c;
+      c.row0 = tile_row0 + s * VM_BLOCK_ROWS + wave * VM_WAVE_ROWS;
+      c.n = n;
+      c.lane = lane;
+      c.active = in_range_bits(c.row0, lane, n);
+      uint32_t sel = 0;
+      if (c.row0 < n) {
+        ColCache K;
+        cache_fill_static<Spec, Spec::pred_cache_mask, 0>(A.prog, c, K);
+        Slot S[VM_MAX_DEPTH];
+        eval_static<Spec, Spec::pred_pc>(A.prog, K, S);
+        sel = c.active & S[0].valid & bool_bits(S[0]);
+      }
+      mask |= sel << (4 * s);
+      const uint32_t cnt = popc_sel(sel);
+      if (lane == 0) s_cnt[s * VM_BLOCK_WAVES + wave] = cnt;
+    }
+    __syncthreads();
+    uint32_t pref[FILTER_STEPS];
+    uint32_t run = 0;
+#pragma unroll
+    for (int i = 0; i < FILTER_STEPS * VM_BLOCK_WAVES; ++i) {
+      if ((uint32_t)(i & (VM_BLOCK_WAVES - 1)) == wave) pref[i / VM_BLOCK_WAVES] = run;
+      run += s_cnt[i];
+    }
+    if (wave == 0) {
+      unsigned long long excl = lookback_exclusive(status, tile, run, lane, &A.scratch->error);
+      if (lane == 0) {
+        s_base = excl;
+        if (tile == A.n_tiles - 1) A.scratch->total = excl + run;
+      }
+    }
+    __syncthreads();
+    const unsigned long long base = s_base;
+#pragma unroll
+    for (int s = 0; s < FILTER_STEPS; ++s) {
+      const uint32_t sel = (mask >> (4 * s)) & 0xFu;
+      if (__ballot(sel != 0) == 0) continue;
+      RowCtx c;
+      c.row0 = tile_row0 + s * VM_BLOCK_ROWS + wave * VM_WAVE_ROWS;
+      c.n = n;
+      c.lane = lane;
+      c.active = sel;  // selected rows only: unselected lanes issue no load
+      ColCache K;
+      cache_fill_static<Spec, Spec::out_cache_mask, 0>(A.prog, c, K);
+      uint32_t rank[VM_R];
+      rank_rows(sel, rank);
+      filter_outs_static<Spec, 0>(A, K, base + pref[s], sel, rank);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- aggregate
+template <class Spec, int T>
+__device__ __forceinline__ void agg_tasks_static(const AggArgs &A, const LdsTable &L, RowCtx &c, const ColCache &K, AggRows &G,
+                                                 uint32_t lane) {
+  if constexpr (T < Spec::n_tasks) {
+    constexpr uint32_t role = Spec::task_role[T], idx = Spec::task_idx[T];
+    Slot S[VM_MAX_DEPTH];
+    S[0].valid = 0xFu;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) S[0].v[j] = 1;
+    if constexpr (Spec::task_eval[T] != 0) eval_static<Spec, Spec::task_pc[T]>(A.prog, K, S);
+    if constexpr (role == ROLE_PRED) {
+      c.active &= S[0].valid & bool_bits(S[0]);
+      if (__ballot(c.active != 0) == 0) return;  // nothing of this wave-step survives the filter
+    } else if constexpr (role == ROLE_KEY) {
+      c.active &= S[0].valid;
+      constexpr uint32_t kbits = Spec::key_bits[idx], sh = Spec::key_shift[idx];
+      constexpr uint64_t fmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) G.key[j] |= (S[0].v[j] & fmask) << sh;
+    } else if constexpr (role == ROLE_LOOKUP) {
+      agg_lookup(L, A.table, c.active, lane, G);
+    } else {
+      agg_fold(L, A.table, idx, Spec::acc_op[idx], Spec::acc_type[idx], Spec::acc_track[idx] != 0, S[0], G, lane);
+    }
+    agg_tasks_static<Spec, T + 1>(A, L, c, K, G, lane);
+  }
+}
+
+template <class Spec>
+__global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_aggregate_static(const AggArgs A) {
+  extern __shared__ unsigned long long lds_raw[];
+  const uint32_t lane = lane_id();
+  const uint32_t wave = threadIdx.x >> 6;
+  const int64_t n = A.n_rows;
+  LdsTable L;
+  agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, Spec::n_accs);
+  agg_lds_clear(L, A.accs, Spec::n_accs);
+
+  const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
+  for (int64_t ws = (int64_t)blockIdx.x * VM_BLOCK_WAVES + wave; ws < nsteps;
+       ws += (int64_t)gridDim.x * VM_BLOCK_WAVES) {
+    RowCtx c;
+    c.row0 = ws * VM_WAVE_ROWS;
+    c.n = n;
+    c.lane = lane;
+    c.active = in_range_bits(c.row0, lane, n);
+    ColCache K;
+    cache_fill_static<Spec, (1u << Spec::cache_n) - 1u, 0>(A.prog, c, K);
+    AggRows G;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) G.key[j] = 0, G.slot[j] = SLOT_NONE;
+    G.rem = 0;
+    G.lead_mb = 0;
+    G.lead_slot = SLOT_NONE;
+    agg_tasks_static<Spec, 0>(A, L, c, K, G, lane);
+  }
+  agg_flush(L, A.table, A.accs, Spec::n_accs);
+}
+
+}  // namespace qe

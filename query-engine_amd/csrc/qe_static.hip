@@ -1,0 +1,86 @@
+// Registry of the kernels built ahead of time for one exact launch shape each.  The shapes come
+// from qe_static_specs.h, which tools/gen_static_specs.py writes by running the host lowering
+// (qe_lowering_describe) on a list of plans: no shape is written by hand, so a Spec can never
+// disagree with what the host would hand the interpreter for the same plan.
+#include <cstring>
+
+#include "qe_signature.h"
+#include "qe_static.h"
+#include "qe_static_specs.h"
+
+namespace qe {
+namespace {
+
+struct Entry {
+  const char *name;
+  const uint32_t *sig;
+  int n_sig;
+  void (*project)(const ProjectArgs &, int, hipStream_t);
+  void (*filter)(const FilterArgs &, int, hipStream_t);
+  void (*aggregate)(const AggArgs &, int, size_t, hipStream_t);
+};
+
+template <class Spec>
+void run_project(const ProjectArgs &a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(qe_project_static<Spec>, dim3(grid), dim3(VM_BLOCK_THREADS), 0, s, a);
+}
+template <class Spec>
+void run_filter(const FilterArgs &a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(qe_filter_static<Spec>, dim3(grid), dim3(VM_BLOCK_THREADS), 0, s, a);
+}
+template <class Spec>
+void run_aggregate(const AggArgs &a, int grid, size_t lds, hipStream_t s) {
+  hipLaunchKernelGGL(qe_aggregate_static<Spec>, dim3(grid), dim3(VM_BLOCK_THREADS), lds, s, a);
+}
+
+#define QE_ENTRY_PROJECT(S) Entry{S::name, S::sig, S::n_sig, run_project<S>, nullptr, nullptr},
+#define QE_ENTRY_FILTER(S) Entry{S::name, S::sig, S::n_sig, nullptr, run_filter<S>, nullptr},
+#define QE_ENTRY_AGGREGATE(S) Entry{S::name, S::sig, S::n_sig, nullptr, nullptr, run_aggregate<S>},
+
+const Entry g_entries[] = {
+    QE_STATIC_PROJECT_SPECS(QE_ENTRY_PROJECT) QE_STATIC_FILTER_SPECS(QE_ENTRY_FILTER)
+        QE_STATIC_AGGREGATE_SPECS(QE_ENTRY_AGGREGATE) Entry{nullptr, nullptr, 0, nullptr, nullptr, nullptr}};
+
+const Entry *find(const std::vector<uint32_t> &sig) {
+  for (const Entry *e = g_entries; e->name; ++e)
+    if ((size_t)e->n_sig == sig.size() && std::memcmp(e->sig, sig.data(), sig.size() * sizeof(uint32_t)) == 0) return e;
+  return nullptr;
+}
+
+}  // namespace
+
+bool static_launch_project(const ProjectArgs &args, int grid, hipStream_t stream, hipError_t *err, const char **kernel_name) {
+  if (!cached_columns_all_valid(args.prog)) return false;
+  const Entry *e = find(signature(args));
+  if (!e || !e->project) return false;
+  e->project(args, grid, stream);
+  *err = hipGetLastError();
+  if (kernel_name) *kernel_name = e->name;
+  return true;
+}
+
+bool static_launch_filter(const FilterArgs &args, int grid, hipStream_t stream, hipError_t *err, const char **kernel_name) {
+  if (!cached_columns_all_valid(args.prog)) return false;
+  const Entry *e = find(signature(args));
+  if (!e || !e->filter) return false;
+  e->filter(args, grid, stream);
+  *err = hipGetLastError();
+  if (kernel_name) *kernel_name = e->name;
+  return true;
+}
+
+bool static_launch_aggregate(const AggArgs &args, int grid, size_t lds_bytes, hipStream_t stream, hipError_t *err,
+                             const char **kernel_name) {
+  if (!cached_columns_all_valid(args.prog)) return false;
+  const Entry *e = find(signature(args));
+  if (!e || !e->aggregate) return false;
+  e->aggregate(args, grid, lds_bytes, stream);
+  *err = hipGetLastError();
+  if (kernel_name) *kernel_name = e->name;
+  return true;
+}
+
+int static_kernel_count() { return (int)(sizeof(g_entries) / sizeof(g_entries[0])) - 1; }
+const char *static_kernel_name(int i) { return i >= 0 && i < static_kernel_count() ? g_entries[i].name : nullptr; }
+
+}  // namespace qe

@@ -1,0 +1,128 @@
+"""The kernels built ahead of time for one launch shape each (qe_static.hip) against the oracle, and
+against the general interpreter kernels on the same plans.  Every case checks, through the launch
+profile, that the path it means to test is the one that ran."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from test_gpu_parity import C, mk, rng, run_agg, run_both
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 255, 1024, 4097, 100_003]
+GT = ("gt", C(3), ("f64", 0.5))
+FMA = ("add", C(1), ("mul", C(2), C(3)))
+
+
+def kabc(n, seed, n_keys=10, key_dtype=np.int64):
+    """k (skewed, no nulls), a, b in [-1, 1), c in [0, 1): the headline table's shape."""
+    r = rng(seed)
+    k = np.minimum(r.geometric(0.6, n) - 1, n_keys - 1).astype(key_dtype)
+    t = orc.INT64 if key_dtype == np.int64 else orc.INT32
+    return [orc.Array(t, k), orc.Array(orc.FLOAT64, r.uniform(-1, 1, n)), orc.Array(orc.FLOAT64, r.uniform(-1, 1, n)),
+            orc.Array(orc.FLOAT64, r.uniform(0, 1, n))]
+
+
+def both_paths(qe, ctx, fn, expect_kernel):
+    """Runs fn() on the specialised path and on the interpreter path; returns both results."""
+    ctx.profile(True)
+    try:
+        ctx.profile_read()
+        a = fn()
+        names = set(ctx.profile_read())
+        assert any(k.startswith(expect_kernel + "_static<") for k in names), f"specialised {expect_kernel} kernel did not run: {names}"
+        ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_NO_SPECIALIZED_KERNELS)
+        b = fn()
+        names = set(ctx.profile_read())
+        assert not any("_static<" in k for k in names) and any(k == expect_kernel + "_kernel" for k in names), names
+    finally:
+        ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP)
+        ctx.profile(False)
+    return a, b
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_project_and_filter_shapes(qe, ctx, n):
+    cols = kabc(n, seed=n)
+    proj = lambda m, scan: m.ProjectionExec([scan], [mk(m, FMA)])
+    filt = lambda m, scan: m.ProjectionExec([m.SelectionExec([scan], mk(m, GT))], [mk(m, FMA)])
+    filt2 = lambda m, scan: m.ProjectionExec([m.SelectionExec([scan], mk(m, GT))], [mk(m, C(0)), mk(m, FMA)])
+    both_paths(qe, ctx, lambda: run_both(qe, ctx, [cols], proj, what=f"project n={n}"), "qe_project")
+    both_paths(qe, ctx, lambda: run_both(qe, ctx, [cols], filt, what=f"filter n={n}"), "qe_filter")
+    both_paths(qe, ctx, lambda: run_both(qe, ctx, [cols], filt2, what=f"filter k,fma n={n}"), "qe_filter")
+    # same shape, other column positions: (a, b, c) without the key column
+    abc = cols[1:]
+    proj3 = lambda m, scan: m.ProjectionExec([scan], [mk(m, ("add", C(0), ("mul", C(1), C(2))))])
+    both_paths(qe, ctx, lambda: run_both(qe, ctx, [abc], proj3, what=f"project abc n={n}"), "qe_project")
+
+
+@pytest.mark.parametrize("n,n_keys", [(1, 1), (300, 3), (4097, 10), (100_003, 10), (100_003, 5000), (200_000, 150_000)])
+def test_aggregate_shapes(qe, ctx, n, n_keys):
+    cols = kabc(n, seed=n + n_keys, n_keys=n_keys)
+    if n_keys > 10:
+        cols[0] = orc.Array(orc.INT64, rng(n).integers(-n_keys // 2, n_keys // 2, n))
+    sum_count = [("sum", C(3)), ("count", None)]
+    four = [("sum", C(3)), ("min", C(3)), ("max", C(3)), ("avg", C(3))]
+    both_paths(qe, ctx, lambda: run_agg(qe, ctx, [cols], [C(0)], sum_count, what=f"sum,count n={n} keys={n_keys}"), "qe_aggregate")
+    both_paths(qe, ctx, lambda: run_agg(qe, ctx, [cols], [C(0)], four, what=f"sum,min,max,avg n={n} keys={n_keys}"), "qe_aggregate")
+    # filter -> project -> group by: the projection is substituted into the aggregate's inputs
+    def north_star(m, scan):
+        sel = m.SelectionExec([scan], mk(m, GT))
+        proj = m.ProjectionExec([sel], [mk(m, C(0)), mk(m, FMA)])
+        args = {} if m is orc else {"group_capacity_hint": 2 * n_keys}
+        return m.AggregateExec([proj], [mk(m, C(0))], [mk(m, ("sum", C(1))), mk(m, ("count", None))], **args)
+    parts = [cols, kabc(777, seed=5, n_keys=min(n_keys, 10))]
+    want = list(north_star(orc, orc.ScanExec([orc.Chunk(p) for p in parts])).execute())
+    if not want:
+        return
+
+    def run():
+        # float64 sums: tolerance 1e-12 x sum |v| per group, computed by run_agg's helper on the filtered input
+        return run_agg(qe, ctx, parts, [C(0)], [("sum", FMA), ("count", None)], pred=GT, hint=2 * n_keys, what=f"north star n={n} keys={n_keys}")
+    if any(len(w) for w in want):
+        both_paths(qe, ctx, run, "qe_aggregate")
+        got = list(north_star(qe, qe.ScanExec(ctx, [__import__("util").gpu_batch(qe, ctx, p) for p in parts])).execute())[0]
+        assert got.num_rows == len(want[0])
+
+
+def test_int32_key_and_partial_final(qe, ctx):
+    cols = kabc(50_000, seed=3, key_dtype=np.int32)[:1] + [kabc(50_000, seed=3)[3]]
+    both_paths(qe, ctx, lambda: run_agg(qe, ctx, [cols], [C(0)], [("sum", C(1)), ("count", None)], what="int32 key"), "qe_aggregate")
+    # PARTIAL on two shards + FINAL merge, all three launches on specialised kernels
+    full = kabc(60_000, seed=8)
+    shards = [[orc.Array(a.type, a.values[s]) for a in full] for s in (slice(0, 25_000), slice(25_000, None))]
+    util = __import__("util")
+
+    def run():
+        parts = []
+        for sh in shards:
+            sel = qe.SelectionExec([qe.ScanExec(ctx, [util.gpu_batch(qe, ctx, sh)])], mk(qe, GT))
+            proj = qe.ProjectionExec([sel], [mk(qe, C(0)), mk(qe, FMA)])
+            parts += list(qe.AggregateExec([proj], [mk(qe, C(0))], [mk(qe, ("sum", C(1))), mk(qe, ("count", None))], mode=qe.AGG_MODE_PARTIAL).execute())
+        fin = qe.final_plan(qe.ScanExec(ctx, parts), 1, [mk(qe, ("sum", C(1))), mk(qe, ("count", None))])
+        return list(fin.execute())[0].columns()
+    a, b = both_paths(qe, ctx, run, "qe_aggregate")
+    m = full[3].values > 0.5
+    v = full[1].values + full[2].values * full[3].values
+    for got in (a, b):
+        order = np.argsort(got[0].values)
+        keys = np.unique(full[0].values[m])
+        assert np.array_equal(np.asarray(got[0].values)[order], keys)
+        assert np.array_equal(np.asarray(got[2].values)[order], [int((m & (full[0].values == k)).sum()) for k in keys])
+        for i, k in zip(order, keys):
+            sel = m & (full[0].values == k)
+            assert abs(got[1].values[i] - v[sel].sum()) <= 1e-12 * np.abs(v[sel]).sum()
+
+
+def test_nullable_input_uses_interpreter(qe, ctx):
+    """A validity bitmap on a cached column is outside what the specialised kernels handle."""
+    cols = kabc(5000, seed=1)
+    cols[3] = orc.Array(orc.FLOAT64, cols[3].values, rng(2).random(5000) > 0.2)
+    ctx.profile(True)
+    try:
+        ctx.profile_read()
+        run_both(qe, ctx, [cols], lambda m, scan: m.ProjectionExec([m.SelectionExec([scan], mk(m, GT))], [mk(m, FMA)]), what="nullable filter")
+        run_agg(qe, ctx, [cols], [C(0)], [("sum", C(3)), ("count", None)], what="nullable aggregate")
+        assert not any("_static<" in k for k in ctx.profile_read())
+    finally:
+        ctx.profile(False)

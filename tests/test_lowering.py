@@ -1,0 +1,56 @@
+"""Host lowering without a GPU: qe_lowering_describe, and that the generated Spec header is current."""
+import importlib
+import importlib.util
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_describe_north_star(qe):
+    C, F = qe.ColumnExpression, qe.LiteralFloatExpression
+    d = qe.describe_lowering([qe.TYPE_INT64] + [qe.TYPE_FLOAT64] * 3, predicate=qe.GtExpression(C(3), F(0.5)),
+                             exprs=[C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))], group_exprs=[C(0)],
+                             agg_exprs=[qe.SumExpression(C(1)), qe.CountExpression(None)])
+    (launch,) = d["launches"]
+    assert launch["kind"] == "aggregate"
+    assert [t["role"] for t in launch["tasks"]] == [1, 2, 3, 4]  # predicate, key, lookup, one accumulator (COUNT(*) = row count)
+    assert launch["keys"] == [{"type": qe.TYPE_INT64, "shift": 0, "bits": 64}]
+    assert launch["accs"] == [{"op": 2, "type": qe.TYPE_FLOAT64, "track": 0, "has_input": 1}]
+    assert len(launch["cache_kind"]) == 4  # k, a, b, c each loaded once per wave-step
+    ops = [w & 0xff for w in launch["code"]]
+    assert ops.count(0) == 3  # three expressions, each closed by OP_END
+
+
+def test_describe_filter_and_project_and_errors(qe):
+    C, F = qe.ColumnExpression, qe.LiteralFloatExpression
+    f64 = [qe.TYPE_FLOAT64] * 3
+    fma = lambda: qe.AddExpression(C(0), qe.MulExpression(C(1), C(2)))
+    (p,) = qe.describe_lowering(f64, exprs=[fma()])["launches"]
+    assert p["kind"] == "project" and len(p["outs"]) == 1 and p["outs"][0]["nullable"] == 0
+    (f,) = qe.describe_lowering(f64, predicate=qe.GtExpression(C(2), F(0.5)), exprs=[fma()])["launches"]
+    assert f["kind"] == "filter" and f["pred_cache_mask"] == 1 and f["out_cache_mask"] == 7
+    (fn,) = qe.describe_lowering(f64, [True, False, False], predicate=qe.GtExpression(C(2), F(0.5)), exprs=[fma()])["launches"]
+    assert fn["outs"][0]["nullable"] == 1 and fn["sig"] != f["sig"]
+    # more expressions than one launch holds -> several launches
+    many = qe.describe_lowering(f64, exprs=[qe.AddExpression(C(0), F(float(i))) for i in range(30)])["launches"]
+    assert len(many) == 3 and sum(len(l["outs"]) for l in many) == 30
+    # pass-through columns need no kernel
+    assert qe.describe_lowering(f64, exprs=[C(1)])["launches"] == []
+    try:
+        qe.describe_lowering(f64, exprs=[qe.AddExpression(C(0), qe.ColumnExpression(7))])
+        assert False
+    except qe.QeError as e:
+        assert e.name == "PrimitiveTypeNotSuported"
+
+
+def test_generated_specs_are_current(tmp_path):
+    """qe_static_specs.h must equal what the generator writes from today's lowering."""
+    spec = importlib.util.spec_from_file_location("gen_static_specs", os.path.join(ROOT, "tools", "gen_static_specs.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(gen.OUT).read()
+    gen.OUT = str(tmp_path / "specs.h")
+    gen.main()
+    assert open(gen.OUT).read() == committed, "run tools/gen_static_specs.py and rebuild"
