@@ -60,20 +60,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # QE_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share
+    # devices, the exchange goes through host memory); the measured configuration is nccl = RCCL.
+    backend = os.environ.get("QE_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
+    xdev = dev if backend == "nccl" else torch.device("cpu")
     qe = importlib.import_module("query-engine_amd")
     stream = torch.cuda.current_stream().cuda_stream
     ctx = qe.Context(local_rank, stream=stream)
 
     # ---------------------------------------------------------------- data
     total = args.rows
-    lo, hi = rank * total // world, (rank + 1) * total // world
+    lo, hi = rank * total // world, (rank + 1) * total // world  # = distributed.shard_range
     n = hi - lo
     k = torch.empty(n, dtype=torch.int64, device=dev)
     a = torch.empty(n, dtype=torch.float64, device=dev)
@@ -108,39 +117,21 @@ def main():
         proj = qe.ProjectionExec([sel], [C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
         return qe.AggregateExec([proj], [C(0)], aggs(1), mode=mode, group_capacity_hint=hint)
 
-    # fixed-size exchange buffers: [count | keys | sum | count] per rank
+    # partial tables (key:int64, sum:float64, count:int64) exchanged through fixed-size buffers
     max_g = max(64, 2 * args.groups)
     if world > 1:
-        send_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-        all_cnt = torch.zeros(world, dtype=torch.int64, device=dev)
-        send_i = torch.zeros(2 * max_g, dtype=torch.int64, device=dev)
-        send_f = torch.zeros(max_g, dtype=torch.float64, device=dev)
-        all_i = torch.zeros(world * 2 * max_g, dtype=torch.int64, device=dev)
-        all_f = torch.zeros(world * max_g, dtype=torch.float64, device=dev)
+        from importlib import import_module
+        xch = import_module("query-engine_amd.distributed").PartialExchange(
+            torch, dist, xdev, world, max_g, [torch.int64, torch.float64, torch.int64])
 
     def step():
         part = list(local_plan().execute())[0]
         if world == 1:
             return part
-        g = part.num_rows
-        if g > max_g:
-            raise RuntimeError("more groups than the exchange buffer holds")
-        kd, sd, cd = part.column_desc(0), part.column_desc(1), part.column_desc(2)
-        send_i[:g].copy_(column_as_tensor(torch, kd, qe))
-        send_i[max_g:max_g + g].copy_(column_as_tensor(torch, cd, qe))
-        send_f[:g].copy_(column_as_tensor(torch, sd, qe))
-        send_cnt.fill_(g)
-        # partial-aggregate exchange over xGMI: three small all-gathers (counts, int payload, float payload)
-        dist.all_gather_into_tensor(all_cnt, send_cnt)
-        dist.all_gather_into_tensor(all_i, send_i)
-        dist.all_gather_into_tensor(all_f, send_f)
-        counts = all_cnt.tolist()
-        parts = []
-        for r in range(world):
-            gr = counts[r]
-            base = r * 2 * max_g
-            parts.append(qe.Batch.from_torch(ctx, [all_i[base:base + gr], all_f[r * max_g:r * max_g + gr],
-                                                   all_i[base + max_g:base + max_g + gr]]))
+        cols = [column_as_tensor(torch, part.column_desc(i), qe) for i in range(3)]
+        # the only collective of the plan: all-gather of the partial tables over xGMI
+        tables = xch.exchange(cols)
+        parts = [qe.Batch.from_torch(ctx, [c.to(dev) for c in t]) for t in tables if t[0].shape[0] > 0]
         final = qe.final_plan(qe.ScanExec(ctx, parts), 1, aggs(1), group_capacity_hint=hint)
         return list(final.execute())[0]
 
@@ -162,23 +153,21 @@ def main():
     prof = ctx.profile_read()
     ctx.profile(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = total / (dt / args.steps)
 
-    # dominant kernel: the fused filter+project+aggregate kernel, timed with HIP events on its stream
-    kern = prof.get("qe_aggregate_kernel", {"launches": 0, "ms": 0.0})
-    # FINAL-merge launches are tiny; the local launches are the first len(batches) per step
-    local_launches = len(batches) * args.steps
+    # dominant kernel: the fused filter+project+aggregate kernel, timed with HIP events on its stream.
+    # (The FINAL merge of the N>1 path runs a different, tiny aggregate kernel: it has its own profile entry.)
+    kname, kern = dominant_kernel(prof, "qe_aggregate")
     launches = kern["launches"]
     avg_ms = kern["ms"] / launches if launches else float("nan")
-    if world > 1 and launches > local_launches:
-        # separate the merge launches out by averaging the bytes over local launches only
-        avg_ms = kern["ms"] / local_launches
     rows_per_launch = n / len(batches)
     achieved = BYTES_PER_ROW["c5"] * rows_per_launch / (avg_ms * 1e-3) / 1e9 if launches else float("nan")
+
+    traffic, traffic_src = measured_traffic(kname, rows_per_launch)
 
     out = {
         "metric": "rows/s + % HBM peak: filter->project->GROUP BY SUM, 1/2/4/8 MI355X",
@@ -196,9 +185,9 @@ def main():
         "config": {"workload": "C5: Scan->Selection(c>0.5)->Projection(k, a+b*c)->Aggregate(GROUP BY k; SUM, COUNT)",
                    "rows_total": total, "rows_per_gpu": n, "groups": args.groups, "batch_rows": args.batch_rows,
                    "bytes_per_row": BYTES_PER_ROW["c5"], "partitioning": f"row-range x{world}",
-                   "merge": "rccl all_gather + FINAL aggregate" if world > 1 else "none"},
+                   "merge": f"{'rccl' if backend == 'nccl' else backend} all_gather + FINAL aggregate" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "qe_aggregate_kernel",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kname,
                      "avg_launch_ms": avg_ms, "rows_per_launch": rows_per_launch},
         "pct_hbm_peak_per_gpu": 100.0 * (BYTES_PER_ROW["c5"] * n / (dt / args.steps)) / 1e9 / HBM_PEAK_GBS,
         "kernels": prof,
@@ -219,6 +208,34 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(kernel_name, rows_per_launch):
+    """HBM bytes per launch of the dominant kernel from the PMC passes kept under profiles/ (rocprofv3
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE, one run each, FETCH_SIZE doubled as gfx950 needs for 16-byte-
+    per-lane streams), scaled from that run's launch size to this one's.  None when no summary matches."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_c5_hbm_traffic.json"))):
+        try:
+            with open(path) as f:
+                summ = json.load(f)["summary"]
+        except (OSError, ValueError, KeyError):
+            continue
+        spec = kernel_name.split("<")[-1].rstrip(">")
+        if spec and spec in summ["kernel"]:
+            best = (summ["hbm_bytes_per_launch"] / summ["rows_per_launch"] * rows_per_launch, os.path.relpath(path, ROOT))
+    return best if best else (None, None)
+
+
+def dominant_kernel(prof, prefix):
+    """The profile entry with the most device time among the kernels whose name starts with `prefix`
+    (general interpreter kernel `<prefix>_kernel` or a shape-specialised `<prefix>_static<...>`)."""
+    best = (prefix + "_kernel", {"launches": 0, "ms": 0.0})
+    for name, rec in prof.items():
+        if name.startswith(prefix) and rec["ms"] > best[1]["ms"]:
+            best = (name, rec)
+    return best
 
 
 def timed(ctx, torch, fn, steps, warmup):
@@ -243,7 +260,7 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
     res = {}
 
     def entry(name, rows, dt, prof, kernel, bpr, launches_per_step, extra=None):
-        kk = prof.get(kernel, {"launches": 0, "ms": 0.0})
+        kernel, kk = dominant_kernel(prof, kernel)
         avg = kk["ms"] / kk["launches"] if kk["launches"] else float("nan")
         gbs = bpr * rows / launches_per_step / (avg * 1e-3) / 1e9 if kk["launches"] else float("nan")
         e = {"rows": rows, "rows_per_s": rows / dt, "ms_per_step": dt * 1e3, "kernel": kernel, "avg_launch_ms": avg,
@@ -260,7 +277,7 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
         sel = qe.SelectionExec([qe.ScanExec(ctx, b2)], qe.GtExpression(C(2), qe.LiteralFloatExpression(0.5)))
         return list(qe.ProjectionExec([sel], [qe.AddExpression(C(0), qe.MulExpression(C(1), C(2)))]).execute())[0]
     dt, prof, out = timed(ctx, torch, c2, 5, 2)
-    entry("C2_filter_project_100M", r2, dt, prof, "qe_filter_kernel", BYTES_PER_ROW["c2"], 1, {"rows_out": out.num_rows})
+    entry("C2_filter_project_100M", r2, dt, prof, "qe_filter", BYTES_PER_ROW["c2"], 1, {"rows_out": out.num_rows})
     del out
 
     # C3: SUM(fare), COUNT(*) GROUP BY passenger_count-style key, 500 M rows (key column + one float64)
@@ -272,7 +289,7 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
         return list(qe.AggregateExec([qe.ScanExec(ctx, b3)], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None)],
                                      group_capacity_hint=64).execute())[0]
     dt, prof, out = timed(ctx, torch, c3, 5, 2)
-    entry("C3_groupby_lowcard_500M", r3, dt, prof, "qe_aggregate_kernel", BYTES_PER_ROW["c3"], len(b3), {"groups": out.num_rows})
+    entry("C3_groupby_lowcard_500M", r3, dt, prof, "qe_aggregate", BYTES_PER_ROW["c3"], len(b3), {"groups": out.num_rows})
 
     # C4: 1 M distinct zipf(1.1) Int64 keys, SUM / MIN / MAX / AVG of one float64 column
     r4 = min(n, 500_000_000)
@@ -287,7 +304,7 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
                                      [qe.SumExpression(C(1)), qe.MinExpression(C(1)), qe.MaxExpression(C(1)), qe.AvgExpression(C(1))],
                                      group_capacity_hint=1_100_000).execute())[0]
     dt, prof, out = timed(ctx, torch, c4, 2, 1)
-    entry("C4_groupby_zipf_1Mkeys_500M", r4, dt, prof, "qe_aggregate_kernel", BYTES_PER_ROW["c4"], len(b4), {"groups": out.num_rows})
+    entry("C4_groupby_zipf_1Mkeys_500M", r4, dt, prof, "qe_aggregate", BYTES_PER_ROW["c4"], len(b4), {"groups": out.num_rows})
     return res
 
 

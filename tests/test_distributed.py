@@ -1,0 +1,91 @@
+"""The N > 1 path on CPU: 2 gloo ranks, each aggregating its row range (the oracle stands in for the
+device kernels here), exchanging partial tables through PartialExchange, merging them, and comparing
+with the aggregate of the whole table.  The GPU kernels themselves are covered by the gpu tests; this
+covers sharding, buffer layout, the collective calls and the merge."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _table(n, n_keys, seed):
+    r = np.random.default_rng(seed)
+    k = np.minimum(r.geometric(0.5, n) - 1, n_keys - 1).astype(np.int64) * 7 - 3
+    return k, r.uniform(-1, 1, n), r.uniform(-1, 1, n), r.uniform(0, 1, n)
+
+
+def _worker(rank, world, port, n, n_keys, max_groups, out_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as orc
+    d = importlib.import_module("query-engine_amd.distributed")
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k, a, b, c = _table(n, n_keys, seed=5)
+        lo, hi = d.shard_range(n, rank, world)
+        C = orc.ColumnExpression
+        chunk = orc.Chunk([orc.Array(orc.INT64, k[lo:hi]), orc.Array(orc.FLOAT64, a[lo:hi]), orc.Array(orc.FLOAT64, b[lo:hi]),
+                           orc.Array(orc.FLOAT64, c[lo:hi])])
+        sel = orc.SelectionExec([orc.ScanExec([chunk])], orc.GtExpression(C(3), orc.LiteralFloatExpression(0.5)))
+        proj = orc.ProjectionExec([sel], [C(0), orc.AddExpression(C(1), orc.MulExpression(C(2), C(3)))])
+        part = list(orc.AggregateExec([proj], [C(0)], [orc.SumExpression(C(1)), orc.CountExpression(None)]).execute())
+        cols = [torch.from_numpy(np.ascontiguousarray(x.values)) for x in part[0].arrays] if part else \
+            [torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.float64), torch.zeros(0, dtype=torch.int64)]
+        xch = d.PartialExchange(torch, dist, "cpu", world, max_groups, [torch.int64, torch.float64, torch.int64])
+        for _ in range(2):  # buffers are reused between steps
+            tables = xch.exchange(cols)
+        assert len(tables) == world and tables[rank][0].tolist() == cols[0].tolist()
+        chunks = [orc.Chunk([orc.Array(orc.INT64, t[0].numpy().copy()), orc.Array(orc.FLOAT64, t[1].numpy().copy()),
+                             orc.Array(orc.INT64, t[2].numpy().copy())]) for t in tables if len(t[0])]
+        merged = list(orc.AggregateExec([orc.ScanExec(chunks)], [C(0)], [orc.SumExpression(C(1)), orc.SumExpression(C(2))]).execute())[0]
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), k=merged.arrays[0].values, s=merged.arrays[1].values, c=merged.arrays[2].values)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,n_keys", [(20_001, 10), (3, 2), (5000, 60)])
+def test_two_rank_partial_exchange(tmp_path, n, n_keys):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, n, n_keys, 64, str(tmp_path)), nprocs=world, join=True)
+    k, a, b, c = _table(n, n_keys, seed=5)
+    m = c > 0.5
+    v = a + b * c
+    keys = np.unique(k[m])
+    for rank in range(world):
+        got = np.load(tmp_path / f"rank{rank}.npz")
+        order = np.argsort(got["k"])
+        assert np.array_equal(got["k"][order], keys)
+        assert np.array_equal(got["c"][order], [int((m & (k == key)).sum()) for key in keys])
+        for i, key in zip(order, keys):
+            sel = m & (k == key)
+            assert abs(got["s"][i] - v[sel].sum()) <= 1e-12 * np.abs(v[sel]).sum()
+
+
+def test_exchange_rejects_oversized_table():
+    import torch
+    d = importlib.import_module("query-engine_amd.distributed")
+
+    class NoDist:
+        def all_gather_into_tensor(self, out, inp):
+            out.copy_(inp)
+    x = d.PartialExchange(torch, NoDist(), "cpu", 1, 4, [torch.int64, torch.float64])
+    (t,) = x.exchange([torch.arange(3), torch.ones(3, dtype=torch.float64)])
+    assert t[0].tolist() == [0, 1, 2] and t[1].tolist() == [1.0, 1.0, 1.0]
+    with pytest.raises(RuntimeError):
+        x.exchange([torch.arange(5), torch.ones(5, dtype=torch.float64)])
+    assert d.shard_range(10, 0, 3) == (0, 3) and d.shard_range(10, 2, 3) == (6, 10)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# GPU-box profiling: rocprofv3 kernel stats of the bench command, then PMC passes (HBM traffic) on one
+# launch-sized probe of the same plan.  Each pass is its own run under its own time limit.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/prof
+rm -rf $O && mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python3 -u $R/bench.py --no-cpu > $O/bench_under_prof.json 2> $O/bench_under_prof.err || { tail -20 $O/bench_under_prof.err; exit 1; }
+find $O/bench -name "*kernel_trace*" -delete
+for cfg in ${PMC_CFGS:-c5}; do
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    timeout -s KILL 120 rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_${cfg}_$ctr -o pmc -- python3 -u $R/tools/probe.py $cfg 256000000 2 > $O/pmc_${cfg}_$ctr.log 2>&1 || { tail -20 $O/pmc_${cfg}_$ctr.log; exit 1; }
+  done
+done
+find $O -type f | head -40
