@@ -604,7 +604,7 @@ struct AggIter : Iter {
         lower_aggregate(comp, schema, s.pred ? expr_normalize(s.pred, ctx->flags) : nullptr, bspec, spec, args);
         args.table = table;
         args.n_rows = in.rows;
-        args.lds_cap = aggregate_lds_slots(args.n_accs, ctx->dev);
+        args.lds_cap = aggregate_lds_slots(args.n_accs, ctx->dev, cap_hint);
         args.lds_limit = args.lds_cap - args.lds_cap / 4;
         const char *kname = "qe_aggregate_kernel";
         ctx->prof_begin(kname);

@@ -27,7 +27,7 @@ int64_t filter_num_tiles(int64_t n_rows);
 // Hash aggregate update over one batch.
 hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name = nullptr);
 // LDS bytes per slot for a given accumulator count, and the slot count chosen.
-uint32_t aggregate_lds_slots(int n_accs, const DeviceInfo &dev);
+uint32_t aggregate_lds_slots(int n_accs, const DeviceInfo &dev, int64_t group_hint);
 
 // Fill a fresh global group table with the empty key / accumulator identities.
 hipError_t launch_table_init(const AggTable &table, const VmAcc *accs, int n_accs, hipStream_t stream);
@@ -51,7 +51,7 @@ hipError_t launch_count_zero_bits(const uint32_t *bitmap, int64_t n, unsigned lo
 // Kernels built for one exact launch shape (qe_static.hip).  Each returns false when no such
 // kernel exists for `args`; otherwise it launches, sets *err and *kernel_name, and returns true.
 bool static_launch_project(const ProjectArgs &args, int grid, hipStream_t stream, hipError_t *err, const char **kernel_name);
-bool static_launch_filter(const FilterArgs &args, int grid, hipStream_t stream, hipError_t *err, const char **kernel_name);
+bool static_launch_filter(const FilterArgs &args, int cus, hipStream_t stream, hipError_t *err, const char **kernel_name);
 bool static_launch_aggregate(const AggArgs &args, int grid, size_t lds_bytes, hipStream_t stream, hipError_t *err,
                              const char **kernel_name);
 int static_kernel_count();

@@ -15,6 +15,8 @@
 // kernel instantiates the interpreter ONCE, rare operations share one out-of-line-style copy
 // that works on temporaries, and per-row work that is more than a few instructions long runs in
 // a rolled loop that rotates the four row registers instead of being unrolled four times.
+#include <cstdlib>
+
 #include "qe_device.h"
 
 namespace qe {
@@ -422,6 +424,16 @@ static bool program_needs_full(const VmProgram &P) {
   return false;
 }
 
+// Workgroups per compute unit of each grid-stride kernel.  Defaults from measurement on MI355X; the
+// environment variables exist for tuning runs (read once per process).
+static int tuned(const char *env, int dflt) {
+  const char *v = getenv(env);
+  int x = v ? atoi(v) : 0;
+  return x > 0 ? x : dflt;
+}
+static int project_blocks_per_cu() { static int v = tuned("QE_PROJECT_BLOCKS_PER_CU", 2); return v; }
+static int filter_blocks_per_cu() { static int v = tuned("QE_FILTER_BLOCKS_PER_CU", 8); return v; }
+
 static int grid_for(int64_t work_items, int per_block, int max_blocks) {
   int64_t b = (work_items + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -431,7 +443,7 @@ static int grid_for(int64_t work_items, int per_block, int max_blocks) {
 
 hipError_t launch_project(const ProjectArgs &args, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name) {
   if (args.n_rows <= 0 || args.n_outs <= 0) return hipSuccess;
-  int grid = grid_for(args.n_rows, VM_BLOCK_ROWS, dev.cus * 8);
+  int grid = grid_for(args.n_rows, VM_BLOCK_ROWS, dev.cus * project_blocks_per_cu());
   hipError_t err;
   if (dev.specialised && static_launch_project(args, grid, stream, &err, kernel_name)) return err;
   if (program_needs_full(args.prog))
@@ -452,9 +464,9 @@ hipError_t launch_filter_reset(FilterScratch *scratch, int64_t n_rows, hipStream
 
 hipError_t launch_filter(const FilterArgs &args, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name) {
   if (args.n_rows <= 0) return hipSuccess;
-  int grid = grid_for(args.n_tiles, 1, dev.cus * 8);
+  int grid = grid_for(args.n_tiles, 1, dev.cus * filter_blocks_per_cu());
   hipError_t err;
-  if (dev.specialised && static_launch_filter(args, grid, stream, &err, kernel_name)) return err;
+  if (dev.specialised && static_launch_filter(args, dev.cus, stream, &err, kernel_name)) return err;
   if (program_needs_full(args.prog))
     hipLaunchKernelGGL(qe_filter_kernel<true>, dim3(grid), dim3(VM_BLOCK_THREADS), 0, stream, args);
   else
@@ -467,18 +479,33 @@ static size_t agg_lds_bytes(int n_accs, uint32_t slots) {
   return stride * 8 + stride * 8 * n_accs + stride * 4 + stride * 4 * n_accs + 16;
 }
 
-uint32_t aggregate_lds_slots(int n_accs, const DeviceInfo &dev) {
-  size_t budget = 64 * 1024;  // two workgroups per CU keep 128 of the 160 KiB
+// LDS table slots.  A table much larger than the number of groups only costs occupancy (with a
+// 64 KiB table two workgroups fit a compute unit; a low-cardinality aggregate with a 1024-slot table
+// runs four and measures 20-45 % faster), so the caller's group-count hint sizes it: 4 x hint slots,
+// at least 256.  Without a hint the cardinality is unknown and the table takes the full budget.
+uint32_t aggregate_lds_slots(int n_accs, const DeviceInfo &dev, int64_t group_hint) {
+  size_t budget = 64 * 1024;
   if ((size_t)dev.max_lds < budget) budget = dev.max_lds;
   uint32_t slots = 4096;
-  while (slots > 16 && agg_lds_bytes(n_accs, slots) > budget) slots >>= 1;
+  static int cap = tuned("QE_AGGREGATE_LDS_SLOTS", 4096);
+  while (slots > 16 && (agg_lds_bytes(n_accs, slots) > budget || slots > (uint32_t)cap)) slots >>= 1;
+  if (group_hint > 0) {
+    uint64_t want = 256;
+    while (want < (uint64_t)group_hint * 4 && want < slots) want <<= 1;
+    if (want < slots) slots = (uint32_t)want;
+  }
   return slots;
 }
 
 hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name) {
   if (args.n_rows <= 0) return hipSuccess;
   size_t lds = agg_lds_bytes(args.n_accs, args.lds_cap);
-  int grid = grid_for(args.n_rows, VM_BLOCK_ROWS, dev.cus * 2);
+  // resident workgroups per compute unit: as many as the LDS tables allow, at most 4
+  int per_cu = (int)((size_t)144 * 1024 / (lds + 512));
+  per_cu = per_cu < 2 ? 2 : per_cu > 4 ? 4 : per_cu;
+  static int forced = tuned("QE_AGGREGATE_BLOCKS_PER_CU", 0);
+  if (forced > 0) per_cu = forced;
+  int grid = grid_for(args.n_rows, VM_BLOCK_ROWS, dev.cus * per_cu);
   hipError_t err;
   if (dev.specialised && static_launch_aggregate(args, grid, lds, stream, &err, kernel_name)) return err;
   if (program_needs_full(args.prog))

@@ -18,24 +18,24 @@ __device__ __forceinline__ void cache_load_static(const VmCol &col, const RowCtx
   if constexpr (KIND == CK_64) {
     const uint64_t *p = (const uint64_t *)col.values;
     if (a0) {
-      U64x2 t = *(const U64x2 *)(p + r0);
+      U64x2 t = stream_load_pair64(p + r0);
       v[0] = t.x;
       v[1] = t.y;
     }
     if (a1) {
-      U64x2 t = *(const U64x2 *)(p + r1);
+      U64x2 t = stream_load_pair64(p + r1);
       v[2] = t.x;
       v[3] = t.y;
     }
   } else if constexpr (KIND == CK_32) {
     const uint32_t *p = (const uint32_t *)col.values;
     if (a0) {
-      U32x2 t = *(const U32x2 *)(p + r0);
+      U32x2 t = stream_load_pair32(p + r0);
       v[0] = (uint64_t)(int64_t)(int32_t)t.x;
       v[1] = (uint64_t)(int64_t)(int32_t)t.y;
     }
     if (a1) {
-      U32x2 t = *(const U32x2 *)(p + r1);
+      U32x2 t = stream_load_pair32(p + r1);
       v[2] = (uint64_t)(int64_t)(int32_t)t.x;
       v[3] = (uint64_t)(int64_t)(int32_t)t.y;
     }
@@ -127,50 +127,73 @@ __device__ __forceinline__ void filter_outs_static(const FilterArgs &A, const Co
   }
 }
 
-// Same tile / ticket / look-back protocol as qe_filter_kernel, with both phases specialised.
+// Tile geometry of the specialised filter kernel.  What a tile costs beyond its bytes is fixed:
+// one ticket, two barriers, one look-back whose walk is as long as the number of tiles in flight
+// on the chip.  Measured on MI355X (c > 0.5 -> a + b*c, 256 M rows): 4096-row tiles with three
+// 256-thread workgroups per compute unit 1.72 ms; 8192-row tiles with ONE 1024-thread workgroup per
+// compute unit 1.34 ms (the same kernel without any look-back: 1.24 ms).  So: big tiles, few of
+// them in flight.  A 1024-thread workgroup leaves 128 registers per lane, enough for two steps of
+// up to three cached columns; wider shapes use 512 threads (256 registers) and more steps.
 template <class Spec>
-__global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_filter_static(const FilterArgs A) {
+struct FilterGeometry {
+  static constexpr int WAVES = Spec::cache_n <= 3 ? 16 : 8;
+  static constexpr int STEPS = Spec::cache_n <= 3 ? 2 : Spec::cache_n <= 5 ? 4 : 3;
+  static constexpr int STEP_ROWS = WAVES * VM_WAVE_ROWS;
+  static constexpr int TILE_ROWS = STEPS * STEP_ROWS;
+};
+
+// Same ticket / look-back protocol as qe_filter_kernel.  The loads of all steps of a phase are
+// issued back to back: a tile costs three dependent trips to memory (ticket, predicate columns,
+// look-back with the remaining output columns in flight) however many steps it has.  Columns the
+// predicate loaded stay in registers for the output expressions.
+template <class Spec>
+__global__ __launch_bounds__(FilterGeometry<Spec>::WAVES * 64, 1) void qe_filter_static(const FilterArgs A) {
+  using G = FilterGeometry<Spec>;
+  constexpr int STEPS = G::STEPS, WAVES = G::WAVES;
   __shared__ unsigned long long s_tile;
   __shared__ unsigned long long s_base;
-  __shared__ uint32_t s_cnt[FILTER_STEPS * VM_BLOCK_WAVES];
+  __shared__ uint32_t s_cnt[STEPS * WAVES];
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   const int64_t n = A.n_rows;
   unsigned long long *status = (unsigned long long *)(A.scratch + 1);
+  constexpr uint32_t PRED_MASK = Spec::pred_cache_mask;
+  constexpr uint32_t LATE_MASK = Spec::out_cache_mask & ~Spec::pred_cache_mask;
 
   for (;;) {
     if (threadIdx.x == 0) s_tile = atomicAdd(&A.scratch->ticket, 1ull);
     __syncthreads();
     const int64_t tile = (int64_t)s_tile;
     if (tile >= A.n_tiles) break;
-    const int64_t tile_row0 = tile * FILTER_TILE_ROWS;
 
-    uint32_t mask = 0;
+    ColCache K[STEPS];
+    RowCtx c[STEPS];
 #pragma unroll
-    for (int s = 0; s < FILTER_STEPS; ++s) {
-      RowCtx c;
-      c.row0 = tile_row0 + s * VM_BLOCK_ROWS + wave * VM_WAVE_ROWS;
-      c.n = n;
-      c.lane = lane;
-      c.active = in_range_bits(c.row0, lane, n);
-      uint32_t sel = 0;
-      if (c.row0 < n) {
-        ColCache K;
-        cache_fill_static<Spec, Spec::pred_cache_mask, 0>(A.prog, c, K);
-        Slot S[VM_MAX_DEPTH];
-        eval_static<Spec, Spec::pred_pc>(A.prog, K, S);
-        sel = c.active & S[0].valid & bool_bits(S[0]);
-      }
-      mask |= sel << (4 * s);
-      const uint32_t cnt = popc_sel(sel);
-      if (lane == 0) s_cnt[s * VM_BLOCK_WAVES + wave] = cnt;
+    for (int s = 0; s < STEPS; ++s) {
+      c[s].row0 = tile * G::TILE_ROWS + s * G::STEP_ROWS + wave * VM_WAVE_ROWS;
+      c[s].n = n;
+      c[s].lane = lane;
+      c[s].active = in_range_bits(c[s].row0, lane, n);
+      cache_fill_static<Spec, PRED_MASK, 0>(A.prog, c[s], K[s]);
+    }
+    uint32_t sel[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      Slot S[VM_MAX_DEPTH];
+      eval_static<Spec, Spec::pred_pc>(A.prog, K[s], S);
+      sel[s] = c[s].active & S[0].valid & bool_bits(S[0]);
+      const uint32_t cnt = popc_sel(sel[s]);
+      if (lane == 0) s_cnt[s * WAVES + wave] = cnt;
+      // the remaining output columns, for selected rows only; in flight during the look-back
+      c[s].active = sel[s];
+      cache_fill_static<Spec, LATE_MASK, 0>(A.prog, c[s], K[s]);
     }
     __syncthreads();
-    uint32_t pref[FILTER_STEPS];
+    uint32_t pref[STEPS];
     uint32_t run = 0;
 #pragma unroll
-    for (int i = 0; i < FILTER_STEPS * VM_BLOCK_WAVES; ++i) {
-      if ((uint32_t)(i & (VM_BLOCK_WAVES - 1)) == wave) pref[i / VM_BLOCK_WAVES] = run;
+    for (int i = 0; i < STEPS * WAVES; ++i) {
+      if ((uint32_t)(i % WAVES) == wave) pref[i / WAVES] = run;
       run += s_cnt[i];
     }
     if (wave == 0) {
@@ -183,19 +206,11 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_filter_static(const Fi
     __syncthreads();
     const unsigned long long base = s_base;
 #pragma unroll
-    for (int s = 0; s < FILTER_STEPS; ++s) {
-      const uint32_t sel = (mask >> (4 * s)) & 0xFu;
-      if (__ballot(sel != 0) == 0) continue;
-      RowCtx c;
-      c.row0 = tile_row0 + s * VM_BLOCK_ROWS + wave * VM_WAVE_ROWS;
-      c.n = n;
-      c.lane = lane;
-      c.active = sel;  // selected rows only: unselected lanes issue no load
-      ColCache K;
-      cache_fill_static<Spec, Spec::out_cache_mask, 0>(A.prog, c, K);
+    for (int s = 0; s < STEPS; ++s) {
+      if (__ballot(sel[s] != 0) == 0) continue;
       uint32_t rank[VM_R];
-      rank_rows(sel, rank);
-      filter_outs_static<Spec, 0>(A, K, base + pref[s], sel, rank);
+      rank_rows(sel[s], rank);
+      filter_outs_static<Spec, 0>(A, K[s], base + pref[s], sel[s], rank);
     }
   }
 }

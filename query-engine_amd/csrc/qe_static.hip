@@ -25,8 +25,14 @@ void run_project(const ProjectArgs &a, int grid, hipStream_t s) {
   hipLaunchKernelGGL(qe_project_static<Spec>, dim3(grid), dim3(VM_BLOCK_THREADS), 0, s, a);
 }
 template <class Spec>
-void run_filter(const FilterArgs &a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(qe_filter_static<Spec>, dim3(grid), dim3(VM_BLOCK_THREADS), 0, s, a);
+void run_filter(const FilterArgs &a, int cus, hipStream_t s) {
+  // tiles are larger than the interpreter kernel's (whose count sized the status array: enough),
+  // and one workgroup per compute unit keeps the look-back walks short
+  using G = FilterGeometry<Spec>;
+  FilterArgs b = a;
+  b.n_tiles = (a.n_rows + G::TILE_ROWS - 1) / G::TILE_ROWS;
+  int64_t grid = b.n_tiles < cus ? b.n_tiles : cus;
+  hipLaunchKernelGGL(qe_filter_static<Spec>, dim3((unsigned)grid), dim3(G::WAVES * 64), 0, s, b);
 }
 template <class Spec>
 void run_aggregate(const AggArgs &a, int grid, size_t lds, hipStream_t s) {
@@ -59,11 +65,11 @@ bool static_launch_project(const ProjectArgs &args, int grid, hipStream_t stream
   return true;
 }
 
-bool static_launch_filter(const FilterArgs &args, int grid, hipStream_t stream, hipError_t *err, const char **kernel_name) {
+bool static_launch_filter(const FilterArgs &args, int cus, hipStream_t stream, hipError_t *err, const char **kernel_name) {
   if (!cached_columns_all_valid(args.prog)) return false;
   const Entry *e = find(signature(args));
   if (!e || !e->filter) return false;
-  e->filter(args, grid, stream);
+  e->filter(args, cus, stream);
   *err = hipGetLastError();
   if (kernel_name) *kernel_name = e->name;
   return true;
