@@ -741,6 +741,7 @@ __device__ __forceinline__ int64_t global_find_or_claim(const AggTable &T, uint6
   }
   uint64_t mask = T.cap - 1;
   uint64_t s = (h >> 20) & mask;
+#pragma unroll 1
   for (uint64_t p = 0; p <= mask; ++p) {
     unsigned long long cur = __hip_atomic_load(&T.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == key) return (int64_t)s;
@@ -768,12 +769,16 @@ __device__ __forceinline__ uint32_t hash32(uint64_t key) {
 }
 
 // LDS slot of `key` (claiming one if new), or -1 when the key does not fit the LDS table.
+// The general case: linear probing with a claim by compare-swap.  Kept as a rolled loop: it runs
+// for the first rows that meet a key and for home-slot collisions, the hot case is
+// lds_probe_home below.
 __device__ __forceinline__ int32_t lds_find_or_claim(const LdsTable &L, uint64_t key) {
   if (key == AGG_EMPTY_KEY) {
     (void)atomicCAS(&L.keys[L.cap], AGG_EMPTY_KEY, 0ull);
     return (int32_t)L.cap;
   }
   uint32_t s = hash32(key) & (L.cap - 1);
+#pragma unroll 1
   for (int p = 0; p < LDS_MAX_PROBE; ++p) {
     unsigned long long cur = *(volatile unsigned long long *)&L.keys[s];
     if (cur == key) return (int32_t)s;
@@ -789,6 +794,25 @@ __device__ __forceinline__ int32_t lds_find_or_claim(const LdsTable &L, uint64_t
     s = (s + 1) & (L.cap - 1);
   }
   return -1;
+}
+
+// The hot case of the lookup: the key already sits in its home slot.  One LDS read, no loop;
+// the reads of a lane's four rows are issued together.  SLOT_PENDING = not found this way.
+constexpr int32_t SLOT_PENDING = INT32_MIN + 1;
+__device__ __forceinline__ void lds_probe_home(const LdsTable &L, const uint64_t (&key)[VM_R], uint32_t rows, int32_t (&slot)[VM_R]) {
+  uint32_t h[VM_R];
+  unsigned long long cur[VM_R];
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    h[j] = hash32(key[j]) & (L.cap - 1);
+    cur[j] = AGG_EMPTY_KEY;
+    if ((rows >> j) & 1u) cur[j] = *(volatile unsigned long long *)&L.keys[h[j]];
+  }
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    slot[j] = SLOT_NONE;
+    if ((rows >> j) & 1u) slot[j] = (cur[j] == key[j] && key[j] != AGG_EMPTY_KEY) ? (int32_t)h[j] : SLOT_PENDING;
+  }
 }
 
 __device__ __forceinline__ void acc_apply(unsigned long long *p, uint32_t op, uint64_t v) {
@@ -848,10 +872,11 @@ struct AggRows {
 };
 
 // Finds / claims the group slot of every active row and counts the rows in.
+template <bool TRY_LEADER = true>
 __device__ __forceinline__ void agg_lookup(const LdsTable &L, const AggTable &T, uint32_t active, uint32_t lane, AggRows &G) {
   uint32_t rem = active;
   // ---- a key that dominates the wave-step?  Try the first row of up to two lanes.
-  uint64_t ball = __ballot(rem != 0);
+  uint64_t ball = TRY_LEADER ? __ballot(rem != 0) : 0ull;
   uint64_t k0 = 0;
   uint32_t lead_cnt = 0, lead_mb = 0;
   int src = 0;
@@ -878,13 +903,29 @@ __device__ __forceinline__ void agg_lookup(const LdsTable &L, const AggTable &T,
     ball &= ~__ballot(mb != 0);  // next candidate: a lane none of whose rows matched
   }
   rem &= ~lead_mb;
-  // ---- LDS slots: the dominant key (one lane) and the remaining rows, back to back
+  // ---- LDS slots.  First the cheap probe of every row's home slot (and of the dominant key's,
+  // by every lane: the value is wave-uniform), then the full lookup for what that left over.
   int32_t lsl = SLOT_NONE;
-  if (lead_cnt != 0 && (int)lane == src) lsl = lds_find_or_claim(L, k0);
+  {
+    const uint32_t hl = hash32(k0) & (L.cap - 1);
+    unsigned long long curl = AGG_EMPTY_KEY;
+    if (lead_cnt != 0) curl = *(volatile unsigned long long *)&L.keys[hl];
+    lds_probe_home(L, G.key, rem, G.slot);
+    if (lead_cnt != 0 && (int)lane == src) lsl = (curl == k0 && k0 != AGG_EMPTY_KEY) ? (int32_t)hl : SLOT_PENDING;
+  }
+  uint32_t pend = 0;
 #pragma unroll
-  for (int j = 0; j < VM_R; ++j) {
-    G.slot[j] = SLOT_NONE;
-    if ((rem >> j) & 1u) G.slot[j] = lds_find_or_claim(L, G.key[j]);
+  for (int j = 0; j < VM_R; ++j)
+    if (G.slot[j] == SLOT_PENDING) pend |= 1u << j;
+  if (__ballot(pend != 0 || lsl == SLOT_PENDING) != 0) {
+    if (lsl == SLOT_PENDING) lsl = lds_find_or_claim(L, k0);
+#pragma unroll 1
+    for (int it = 0; it < VM_R; ++it) {
+      if (pend & 1u) G.slot[0] = lds_find_or_claim(L, G.key[0]);
+      pend = rot4(pend);
+      QE_ROT4(G.key);
+      QE_ROT4(G.slot);
+    }
   }
   // ---- keys the LDS table has no room for go to the global table (rare: rolled loop)
   uint32_t miss = 0;

@@ -56,6 +56,18 @@ __device__ __forceinline__ void cache_fill_static(const VmProgram &P, const RowC
   }
 }
 
+template <class Spec, uint32_t MASK, int I>
+__device__ __forceinline__ void cache_copy_static(ColCache &dst, const ColCache &src) {
+  if constexpr (I < Spec::cache_n) {
+    if constexpr ((MASK >> I) & 1u) {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) dst.v[I][j] = src.v[I][j];
+      dst.valid[I] = src.valid[I];
+    }
+    cache_copy_static<Spec, MASK, I + 1>(dst, src);
+  }
+}
+
 template <class Spec, int PC>
 __device__ __forceinline__ void eval_static(const VmProgram &P, const ColCache &K, Slot (&S)[VM_MAX_DEPTH]) {
   constexpr uint32_t ins = Spec::code[PC];
@@ -216,9 +228,164 @@ __global__ __launch_bounds__(FilterGeometry<Spec>::WAVES * 64, 1) void qe_filter
 }
 
 // ---------------------------------------------------------------- aggregate
+// Hot-group cache.  In a low-cardinality or skewed GROUP BY most rows belong to a handful of keys,
+// and sending each of them through an LDS atomic makes the LDS pipeline the limit long before
+// HBM is.  Each wave therefore keeps up to HOT_KEYS keys of its own (wave-uniform) together with
+// PER-LANE partial accumulators for them in registers: a row of a hot key costs a compare and a
+// masked add, no lookup, no atomic, no cross-lane traffic.  The partials are reduced across the
+// wave and added to the global table when the key is replaced and at the end of the kernel.
+// A key becomes hot when it holds at least HOT_MIN_ROWS of the 256 rows of a wave-step; a hot key
+// that gets no row in a wave-step gives way to a new candidate (runs of equal keys).  When several
+// candidates in a row fail the test (high-cardinality uniform keys) the wave stops testing for a
+// while, so the cost there is a few instructions per wave-step.
+constexpr int HOT_KEYS = 2;
+constexpr uint32_t HOT_MIN_ROWS = 12;
+constexpr uint32_t HOT_FAIL_LIMIT = 4;   // failed candidates in a row before backing off
+constexpr uint32_t HOT_BACKOFF_STEPS = 32;
+
+template <int NA>
+struct HotCache {
+  uint64_t key[HOT_KEYS];  // wave-uniform
+  uint32_t valid;          // wave-uniform; bit h: slot h holds a key
+  uint32_t fails;          // wave-uniform; candidates that failed in a row
+  uint32_t pause;          // wave-uniform; wave-steps left without candidate tests
+  uint32_t rows[HOT_KEYS];                  // per lane
+  uint64_t acc[HOT_KEYS][NA > 0 ? NA : 1];  // per lane partial accumulators
+  uint32_t nn[HOT_KEYS][NA > 0 ? NA : 1];   // per lane count of valid inputs
+};
+
+// Clears slot HSLOT's partials when `on` (selects, not stores under a branch: the optimiser merges
+// such stores of different slots into one store with a computed index, and the arrays end up in
+// scratch memory).
+template <class Spec, int HSLOT>
+__device__ __forceinline__ void hot_reset(HotCache<Spec::n_accs> &C, bool on) {
+  C.rows[HSLOT] = on ? 0u : C.rows[HSLOT];
+#pragma unroll
+  for (int a = 0; a < Spec::n_accs; ++a) {
+    C.acc[HSLOT][a] = on ? acc_identity(Spec::acc_op[a]) : C.acc[HSLOT][a];
+    C.nn[HSLOT][a] = on ? 0u : C.nn[HSLOT][a];
+  }
+}
+
+// Wave-wide, `on` wave-uniform: adds slot HSLOT's partials to the global table and clears them.
+template <class Spec, int HSLOT>
+__device__ __forceinline__ void hot_flush(HotCache<Spec::n_accs> &C, const AggTable &T, uint32_t lane, bool on) {
+  if (on) {
+    const uint64_t key = C.key[HSLOT];
+    const unsigned long long rows = wave_sum_u64(C.rows[HSLOT]);
+    long long g = -1;
+    if (lane == 0 && rows != 0) g = global_find_or_claim(T, key, mix64(key));  // full table: flagged for the host
+    if (lane == 0 && g >= 0) atomicAdd(&T.rowcnt[g], rows);
+#pragma unroll
+    for (int a = 0; a < Spec::n_accs; ++a) {
+      const uint32_t op = Spec::acc_op[a];  // constant after unrolling
+      const uint64_t part = wave_reduce_acc(op, C.acc[HSLOT][a]);
+      const unsigned long long nn = wave_sum_u64(C.nn[HSLOT][a]);
+      if (lane == 0 && g >= 0) {
+        if (part != acc_identity(op) || op == ACC_SUM_F64) acc_apply(&T.acc[(uint64_t)a * T.stride + g], op, part);
+        if (Spec::acc_track[a] != 0 && nn != 0) atomicAdd(&T.nn[(uint64_t)a * T.stride + g], nn);
+      }
+    }
+  }
+  hot_reset<Spec, HSLOT>(C, on);
+}
+
+// Rows of the hot keys among `active` (bits per lane) -> hm[]; the other rows are returned.
+// Also runs the install / replace policy.
+template <class Spec>
+__device__ __forceinline__ uint32_t hot_match(HotCache<Spec::n_accs> &C, const AggTable &T, const uint64_t (&key)[VM_R], uint32_t active,
+                                              uint32_t lane, uint32_t (&hm)[HOT_KEYS]) {
+  uint32_t rest = active;
+#pragma unroll
+  for (int h = 0; h < HOT_KEYS; ++h) {
+    hm[h] = 0;
+    if ((C.valid >> h) & 1u) {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j)
+        if (((active >> j) & 1u) && key[j] == C.key[h]) hm[h] |= 1u << j;
+    }
+    rest &= ~hm[h];
+  }
+  if (C.pause != 0) {
+    --C.pause;
+    return rest;
+  }
+  const uint64_t ball = __ballot(rest != 0);
+  if (ball == 0) return rest;
+  // a slot that is free, or whose key got no row in this wave-step
+  int target = -1;
+#pragma unroll
+  for (int h = HOT_KEYS - 1; h >= 0; --h)
+    if (!((C.valid >> h) & 1u)) target = h;
+  if (target < 0) {
+#pragma unroll
+    for (int h = HOT_KEYS - 1; h >= 0; --h)
+      if (__ballot(hm[h] != 0) == 0) target = h;
+  }
+  if (target < 0) return rest;
+  // candidate: the first remaining row of the first lane that has one
+  const int src = __builtin_ctzll(ball);
+  uint64_t kl = opaque64(key[3]);
+  if (rest & 4u) kl = opaque64(key[2]);
+  if (rest & 2u) kl = opaque64(key[1]);
+  if (rest & 1u) kl = opaque64(key[0]);
+  const uint64_t k0 = readlane64(kl, src);
+  uint32_t mb = 0;
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j)
+    if (((rest >> j) & 1u) && key[j] == k0) mb |= 1u << j;
+  if (popc_sel(mb) < HOT_MIN_ROWS) {
+    if (++C.fails >= HOT_FAIL_LIMIT) {
+      C.fails = 0;
+      C.pause = HOT_BACKOFF_STEPS;
+    }
+    return rest;
+  }
+  C.fails = 0;
+  static_assert(HOT_KEYS == 2, "one flush call per slot below");
+  hot_flush<Spec, 0>(C, T, lane, target == 0 && (C.valid & 1u) != 0);
+  hot_flush<Spec, 1>(C, T, lane, target == 1 && (C.valid & 2u) != 0);
+  // selects, not stores under a branch: those get merged into one store with a computed index,
+  // which moves the array to scratch memory
+#pragma unroll
+  for (int h = 0; h < HOT_KEYS; ++h) {
+    C.key[h] = target == h ? k0 : C.key[h];
+    hm[h] = target == h ? mb : hm[h];
+  }
+  C.valid |= 1u << target;
+  return rest & ~mb;
+}
+
+// Folds one evaluated input into the hot keys' per-lane partials (rows hm[h]).
+template <class Spec, int ACC>
+__device__ __forceinline__ void hot_fold(HotCache<Spec::n_accs> &C, const Slot &in, const uint32_t (&hm)[HOT_KEYS]) {
+  constexpr uint32_t op = Spec::acc_op[ACC], in_type = Spec::acc_type[ACC];
+  uint32_t valid = in.valid;
+  uint64_t v[VM_R];
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    uint64_t x = in.v[j];
+    if (op == ACC_MIN || op == ACC_MAX) {
+      if (in_type == VT_F64 && u2d(x) != u2d(x)) valid &= ~(1u << j);  // NaN is ignored by min / max
+      x = ord_image(x, in_type);
+    } else if (op == ACC_COUNT) {
+      x = 1;
+    }
+    v[j] = x;
+  }
+#pragma unroll
+  for (int h = 0; h < HOT_KEYS; ++h) {
+    const uint32_t m = hm[h] & valid;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j)
+      if ((m >> j) & 1u) C.acc[h][ACC] = acc_combine(op, C.acc[h][ACC], v[j]);
+    if (Spec::acc_track[ACC] != 0) C.nn[h][ACC] += (uint32_t)__popc(m);
+  }
+}
+
 template <class Spec, int T>
 __device__ __forceinline__ void agg_tasks_static(const AggArgs &A, const LdsTable &L, RowCtx &c, const ColCache &K, AggRows &G,
-                                                 uint32_t lane) {
+                                                 HotCache<Spec::n_accs> &C, uint32_t (&hm)[HOT_KEYS], uint32_t lane) {
   if constexpr (T < Spec::n_tasks) {
     constexpr uint32_t role = Spec::task_role[T], idx = Spec::task_idx[T];
     Slot S[VM_MAX_DEPTH];
@@ -236,11 +403,17 @@ __device__ __forceinline__ void agg_tasks_static(const AggArgs &A, const LdsTabl
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) G.key[j] |= (S[0].v[j] & fmask) << sh;
     } else if constexpr (role == ROLE_LOOKUP) {
-      agg_lookup(L, A.table, c.active, lane, G);
+      const uint32_t rest = hot_match<Spec>(C, A.table, G.key, c.active, lane, hm);
+#pragma unroll
+      for (int h = 0; h < HOT_KEYS; ++h) C.rows[h] += (uint32_t)__popc(hm[h]);
+      // rows of other keys: LDS / global table (no dominant-key search: the hot keys took those)
+      agg_lookup<false>(L, A.table, rest, lane, G);
     } else {
-      agg_fold(L, A.table, idx, Spec::acc_op[idx], Spec::acc_type[idx], Spec::acc_track[idx] != 0, S[0], G, lane);
+      hot_fold<Spec, (int)idx>(C, S[0], hm);
+      if (__ballot(G.rem != 0) != 0)
+        agg_fold(L, A.table, idx, Spec::acc_op[idx], Spec::acc_type[idx], Spec::acc_track[idx] != 0, S[0], G, lane);
     }
-    agg_tasks_static<Spec, T + 1>(A, L, c, K, G, lane);
+    agg_tasks_static<Spec, T + 1>(A, L, c, K, G, C, hm, lane);
   }
 }
 
@@ -253,6 +426,14 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_aggregate_static(const
   LdsTable L;
   agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, Spec::n_accs);
   agg_lds_clear(L, A.accs, Spec::n_accs);
+
+  HotCache<Spec::n_accs> C;
+  C.valid = 0;
+  C.fails = 0;
+  C.pause = 0;
+  C.key[0] = C.key[1] = 0;
+  hot_reset<Spec, 0>(C, true);
+  hot_reset<Spec, 1>(C, true);
 
   const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
   for (int64_t ws = (int64_t)blockIdx.x * VM_BLOCK_WAVES + wave; ws < nsteps;
@@ -270,8 +451,11 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_aggregate_static(const
     G.rem = 0;
     G.lead_mb = 0;
     G.lead_slot = SLOT_NONE;
-    agg_tasks_static<Spec, 0>(A, L, c, K, G, lane);
+    uint32_t hm[HOT_KEYS] = {0, 0};
+    agg_tasks_static<Spec, 0>(A, L, c, K, G, C, hm, lane);
   }
+  hot_flush<Spec, 0>(C, A.table, lane, (C.valid & 1u) != 0);
+  hot_flush<Spec, 1>(C, A.table, lane, (C.valid & 2u) != 0);
   agg_flush(L, A.table, A.accs, Spec::n_accs);
 }
 
