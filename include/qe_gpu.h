@@ -101,7 +101,14 @@ enum {
   /* Always run the general interpreter kernels, never a kernel that was built
    * ahead of time for the exact shape of a launch.  Results are the same
    * either way; the flag exists for testing and for timing the two paths. */
-  QE_FLAG_NO_SPECIALIZED_KERNELS = 2
+  QE_FLAG_NO_SPECIALIZED_KERNELS = 2,
+  /* Kernels for launch shapes that were not built ahead of time are compiled at
+   * run time.  By default that happens on a background thread, and only for
+   * batches large enough to matter, while the general kernels serve the shape;
+   * with this flag the first launch of a shape compiles and waits, whatever the
+   * batch size (tests, prepared workloads).  The environment variable QE_JIT =
+   * off | async | sync sets the default. */
+  QE_FLAG_JIT_SYNC = 4
 };
 
 typedef struct qe_context qe_context;
@@ -261,6 +268,17 @@ qe_status qe_lowering_describe(const int32_t *col_types, const uint8_t *col_null
                                const qe_expr *const *group_exprs, int32_t n_group_exprs,
                                const qe_agg_expr *const *agg_exprs, int32_t n_agg_exprs, int32_t mode,
                                char *buf, int64_t buf_len, int64_t *needed);
+
+/* Same lowering as qe_lowering_describe; compiles the shape-specialised kernel
+ * of every launch with the HIP run-time compiler (no GPU needed) and reports
+ * how many kernels were built and their total code size.  Launches whose
+ * expressions need the general kernels (division, utf8, casts) are skipped.
+ * No counterpart in the reference. */
+qe_status qe_lowering_compile(const int32_t *col_types, const uint8_t *col_nullable, int32_t n_cols, uint32_t flags,
+                              const qe_expr *predicate, const qe_expr *const *exprs, int32_t n_exprs,
+                              const qe_expr *const *group_exprs, int32_t n_group_exprs,
+                              const qe_agg_expr *const *agg_exprs, int32_t n_agg_exprs, int32_t mode,
+                              int32_t *n_kernels, int64_t *code_bytes);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,7 @@ AGG_MAX, AGG_MIN, AGG_SUM, AGG_COUNT, AGG_AVG = 1, 2, 3, 4, 5
 AGG_MODE_SINGLE, AGG_MODE_PARTIAL, AGG_MODE_FINAL = 0, 1, 2
 FLAG_REFERENCE_SCALAR_ARRAY_SWAP = 1
 FLAG_NO_SPECIALIZED_KERNELS = 2
+FLAG_JIT_SYNC = 4
 
 _NP_OF_TYPE = {TYPE_INT32: np.int32, TYPE_INT64: np.int64, TYPE_FLOAT64: np.float64}
 _TYPE_OF_NP = {np.dtype(np.int32): TYPE_INT32, np.dtype(np.int64): TYPE_INT64, np.dtype(np.float64): TYPE_FLOAT64,
@@ -99,6 +100,9 @@ ABI = {
                                          C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
                                          C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_char_p, C.c_int64,
                                          C.POINTER(C.c_int64)]),
+    "qe_lowering_compile": (C.c_int32, [C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_int32, C.c_uint32, C.c_void_p,
+                                        C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
+                                        C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
 }
 
 
@@ -744,11 +748,7 @@ def final_plan(scan_of_partials, n_group_exprs, agg_exprs, group_capacity_hint=0
     return AggregateExec(scan_of_partials, groups, aggs, mode=AGG_MODE_FINAL, group_capacity_hint=group_capacity_hint)
 
 
-def describe_lowering(col_types, col_nullable=None, predicate=None, exprs=(), group_exprs=(), agg_exprs=(),
-                      mode=AGG_MODE_SINGLE, flags=FLAG_REFERENCE_SCALAR_ARRAY_SWAP):
-    """What Scan(schema) -> [Selection] -> [Projection] -> [Aggregate] compiles to: a dict with one entry per
-    kernel launch (interpreter code, cache layout, sink descriptors, launch signature).  Needs no GPU."""
-    import json
+def _lowering_call(fn, col_types, col_nullable, predicate, exprs, group_exprs, agg_exprs, mode, flags, tail):
     n = len(col_types)
     types = (C.c_int32 * max(1, n))(*col_types)
     nullable = (C.c_uint8 * max(1, n))(*[1 if x else 0 for x in (col_nullable or [False] * n)])
@@ -758,11 +758,7 @@ def describe_lowering(col_types, col_nullable=None, predicate=None, exprs=(), gr
         earr = (C.c_void_p * max(1, len(es)))(*es)
         garr = (C.c_void_p * max(1, len(gs)))(*gs)
         aarr = (C.c_void_p * max(1, len(ags)))(*ags)
-        buf = C.create_string_buffer(1 << 16)
-        need = C.c_int64()
-        _check(lib.qe_lowering_describe(types, nullable, n, flags, pred, earr, len(es), garr, len(gs), aarr, len(ags), mode,
-                                        buf, len(buf), C.byref(need)))
-        return json.loads(buf.value.decode())
+        _check(fn(types, nullable, n, flags, pred, earr, len(es), garr, len(gs), aarr, len(ags), mode, *tail))
     finally:
         if pred is not None:
             lib.qe_expr_free(pred)
@@ -770,3 +766,25 @@ def describe_lowering(col_types, col_nullable=None, predicate=None, exprs=(), gr
             lib.qe_expr_free(h)
         for h in ags:
             lib.qe_agg_expr_free(h)
+
+
+def describe_lowering(col_types, col_nullable=None, predicate=None, exprs=(), group_exprs=(), agg_exprs=(),
+                      mode=AGG_MODE_SINGLE, flags=FLAG_REFERENCE_SCALAR_ARRAY_SWAP):
+    """What Scan(schema) -> [Selection] -> [Projection] -> [Aggregate] compiles to: a dict with one entry per
+    kernel launch (interpreter code, cache layout, sink descriptors, launch signature).  Needs no GPU."""
+    import json
+    buf = C.create_string_buffer(1 << 18)
+    need = C.c_int64()
+    _lowering_call(lib.qe_lowering_describe, col_types, col_nullable, predicate, exprs, group_exprs, agg_exprs, mode, flags,
+                   (buf, len(buf), C.byref(need)))
+    return json.loads(buf.value.decode())
+
+
+def compile_lowering(col_types, col_nullable=None, predicate=None, exprs=(), group_exprs=(), agg_exprs=(),
+                     mode=AGG_MODE_SINGLE, flags=FLAG_REFERENCE_SCALAR_ARRAY_SWAP):
+    """Run-time compiles the shape-specialised kernel of every launch of that pipeline (no GPU needed).
+    Returns (kernels built, total code bytes)."""
+    nk, nb = C.c_int32(), C.c_int64()
+    _lowering_call(lib.qe_lowering_compile, col_types, col_nullable, predicate, exprs, group_exprs, agg_exprs, mode, flags,
+                   (C.byref(nk), C.byref(nb)))
+    return nk.value, nb.value

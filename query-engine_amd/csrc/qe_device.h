@@ -16,7 +16,12 @@
 // that works on temporaries, and per-row work that is more than a few instructions long runs in
 // a rolled loop that rotates the four row registers instead of being unrolled four times.
 #pragma once
-#include "qe_kernels.h"
+// Device code only, written to compile both with hipcc and with the run-time compiler (which
+// provides the HIP device declarations itself).
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>
+#endif
+#include "qe_vm.h"
 
 namespace qe {
 

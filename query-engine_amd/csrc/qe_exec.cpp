@@ -12,7 +12,7 @@
 #include <sstream>
 
 #include "qe_core.h"
-#include "qe_signature.h"
+#include "qe_jit.h"
 
 namespace qe {
 
@@ -758,24 +758,23 @@ static void json_u32s(std::ostringstream &o, const char *key, const std::vector<
   o << "]";
 }
 
-static void describe_program(std::ostringstream &o, const VmProgram &P) {
-  int n = program_words_used(P);
-  json_u32s(o, "code", std::vector<uint32_t>(P.insn, P.insn + n));
-  o << ",";
-  json_u32s(o, "cache_kind", std::vector<uint32_t>(P.cache_kind, P.cache_kind + P.cache_n));
+static std::string json_escape(const std::string &s) {
+  std::string r;
+  for (char ch : s) {
+    if (ch == '"' || ch == '\\') r += '\\', r += ch;
+    else if (ch == '\n') r += "\\n";
+    else r += ch;
+  }
+  return r;
 }
 
-static void describe_outs(std::ostringstream &o, const VmOut *outs, int n) {
-  o << "\"outs\":[";
-  for (int i = 0; i < n; ++i)
-    o << (i ? "," : "") << "{\"pc\":" << outs[i].pc << ",\"type\":" << (int)outs[i].type << ",\"nullable\":" << (outs[i].validity ? 1 : 0) << "}";
-  o << "]";
-}
+using LaunchVisitor = std::function<void(JitKind kind, const SpecFields &f)>;
 
 // Lowers Scan(schema) -> [Selection pred] -> [Projection outs] -> [Aggregate groups, aggs] the way
-// execution does and renders every kernel launch it would make as JSON.  Touches no device.
-static std::string describe_lowering(const Schema &schema, uint32_t flags, const ExprPtr &pred_raw, const std::vector<ExprPtr> &outs_raw,
-                                     const std::vector<ExprPtr> &groups, const std::vector<AggExpr> &aggs, int mode) {
+// execution does and hands every kernel launch it would make to `visit`.  Touches no device.
+static void for_each_lowered_launch(const Schema &schema, uint32_t flags, const ExprPtr &pred_raw, const std::vector<ExprPtr> &outs_raw,
+                                    const std::vector<ExprPtr> &groups, const std::vector<AggExpr> &aggs, int mode,
+                                    const LaunchVisitor &visit) {
   Batch in;
   in.rows = 1 << 20;
   for (size_t i = 0; i < schema.size(); ++i) {
@@ -792,15 +791,6 @@ static std::string describe_lowering(const Schema &schema, uint32_t flags, const
   OutSink sink = [](int, bool nullable, VmOut &o) {
     o.values = (void *)(uintptr_t)0x10;
     o.validity = nullable ? (uint32_t *)(uintptr_t)0x10 : nullptr;
-  };
-  std::ostringstream o;
-  o << "{\"launches\":[";
-  bool first_launch = true;
-  auto open_launch = [&](const char *kind, const std::vector<uint32_t> &sig) {
-    o << (first_launch ? "" : ",") << "{\"kind\":\"" << kind << "\",";
-    json_u32s(o, "sig", sig);
-    o << ",";
-    first_launch = false;
   };
   ExprPtr pred = pred_raw ? expr_normalize(pred_raw, flags) : nullptr;
 
@@ -824,57 +814,79 @@ static std::string describe_lowering(const Schema &schema, uint32_t flags, const
     Compiler comp(nullptr, &in);
     AggArgs args{};
     lower_aggregate(comp, schema, pred, spec, spec, args);
-    open_launch("aggregate", signature(args));
-    describe_program(o, args.prog);
-    o << ",\"tasks\":[";
-    for (int i = 0; i < args.n_tasks; ++i)
-      o << (i ? "," : "") << "{\"pc\":" << args.tasks[i].pc << ",\"role\":" << (int)args.tasks[i].role << ",\"idx\":" << (int)args.tasks[i].idx
-        << ",\"eval\":" << (int)args.tasks[i].has_eval << "}";
-    o << "],\"keys\":[";
-    for (int i = 0; i < args.n_keys; ++i)
-      o << (i ? "," : "") << "{\"type\":" << (int)args.keys[i].type << ",\"shift\":" << (int)args.keys[i].shift << ",\"bits\":" << (int)args.keys[i].bits << "}";
-    o << "],\"accs\":[";
-    for (int i = 0; i < args.n_accs; ++i)
-      o << (i ? "," : "") << "{\"op\":" << (int)args.accs[i].op << ",\"type\":" << (int)args.accs[i].in_type << ",\"track\":" << (int)args.accs[i].track_nn
-        << ",\"has_input\":" << (int)args.accs[i].has_input << "}";
-    o << "]}";
-  } else {
-    std::vector<ExprPtr> outs;
-    for (auto &e : outs_raw) outs.push_back(expr_normalize(e, flags));
-    std::vector<int> types, vm_list;
-    for (auto &e : outs) types.push_back(expr_type(e, schema));
-    for (size_t i = 0; i < outs.size(); ++i) {
-      if (types[i] == QE_TYPE_UTF8) continue;                // gathered / broadcast by separate kernels
-      if (!pred && outs[i]->kind == EK_COLUMN) continue;     // shared with the input, no kernel
-      vm_list.push_back((int)i);
-    }
-    size_t k = 0;
-    bool first = true;
-    while ((pred && first) || k < vm_list.size()) {
-      Compiler comp(nullptr, &in);
-      if (pred) {
-        FilterArgs args{};
-        size_t k2 = lower_filter(comp, schema, pred, outs, types, vm_list, k, in.rows, nullptr, args, sink);
-        if (!first && k2 == k) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression is too long for one kernel.");
-        k = k2;
-        open_launch("filter", signature(args));
-        describe_program(o, args.prog);
-        o << ",";
-        describe_outs(o, args.outs, args.n_outs);
-        o << ",\"pred_pc\":" << args.pred_pc << ",\"pred_cache_mask\":" << args.pred_cache_mask << ",\"out_cache_mask\":" << args.out_cache_mask << "}";
-      } else {
-        ProjectArgs args{};
-        k = lower_project(comp, schema, outs, types, vm_list, k, in.rows, args, sink);
-        open_launch("project", signature(args));
-        describe_program(o, args.prog);
-        o << ",";
-        describe_outs(o, args.outs, args.n_outs);
-        o << "}";
-      }
-      first = false;
-    }
+    visit(JIT_AGGREGATE, spec_fields(args));
+    return;
   }
-  o << "]}";
+  std::vector<ExprPtr> outs;
+  for (auto &e : outs_raw) outs.push_back(expr_normalize(e, flags));
+  std::vector<int> types, vm_list;
+  for (auto &e : outs) types.push_back(expr_type(e, schema));
+  for (size_t i = 0; i < outs.size(); ++i) {
+    if (types[i] == QE_TYPE_UTF8) continue;             // gathered / broadcast by separate kernels
+    if (!pred && outs[i]->kind == EK_COLUMN) continue;  // shared with the input, no kernel
+    vm_list.push_back((int)i);
+  }
+  size_t k = 0;
+  bool first = true;
+  while ((pred && first) || k < vm_list.size()) {
+    Compiler comp(nullptr, &in);
+    if (pred) {
+      FilterArgs args{};
+      size_t k2 = lower_filter(comp, schema, pred, outs, types, vm_list, k, in.rows, nullptr, args, sink);
+      if (!first && k2 == k) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression is too long for one kernel.");
+      k = k2;
+      visit(JIT_FILTER, spec_fields(args));
+    } else {
+      ProjectArgs args{};
+      k = lower_project(comp, schema, outs, types, vm_list, k, in.rows, args, sink);
+      visit(JIT_PROJECT, spec_fields(args));
+    }
+    first = false;
+  }
+}
+
+static std::string describe_launch(JitKind kind, const SpecFields &f) {
+  static const char *names[] = {"project", "filter", "aggregate"};
+  std::ostringstream o;
+  o << "{\"kind\":\"" << names[kind] << "\",";
+  json_u32s(o, "sig", f.sig);
+  o << ",";
+  int n = program_words_used(*f.prog);
+  json_u32s(o, "code", std::vector<uint32_t>(f.prog->insn, f.prog->insn + n));
+  o << ",";
+  std::vector<uint32_t> kinds, nullable;
+  for (uint32_t i = 0; i < f.prog->cache_n; ++i) {
+    kinds.push_back(f.prog->cache_kind[i]);
+    nullable.push_back(f.prog->cols[f.prog->cache_col[i]].validity ? 1u : 0u);
+  }
+  json_u32s(o, "cache_kind", kinds);
+  o << ",";
+  json_u32s(o, "cache_nullable", nullable);
+  o << ",\"specialisable\":" << (program_is_specialisable(*f.prog) ? 1 : 0);
+  if (kind != JIT_AGGREGATE) {
+    o << ",\"outs\":[";
+    for (int i = 0; i < f.n_outs; ++i)
+      o << (i ? "," : "") << "{\"pc\":" << f.outs[i].pc << ",\"type\":" << (int)f.outs[i].type << ",\"nullable\":" << (f.outs[i].validity ? 1 : 0) << "}";
+    o << "]";
+  }
+  if (kind == JIT_FILTER)
+    o << ",\"pred_pc\":" << f.pred_pc << ",\"pred_cache_mask\":" << f.pred_cache_mask << ",\"out_cache_mask\":" << f.out_cache_mask;
+  if (kind == JIT_AGGREGATE) {
+    o << ",\"tasks\":[";
+    for (int i = 0; i < f.n_tasks; ++i)
+      o << (i ? "," : "") << "{\"pc\":" << f.tasks[i].pc << ",\"role\":" << (int)f.tasks[i].role << ",\"idx\":" << (int)f.tasks[i].idx
+        << ",\"eval\":" << (int)f.tasks[i].has_eval << "}";
+    o << "],\"keys\":[";
+    for (int i = 0; i < f.n_keys; ++i)
+      o << (i ? "," : "") << "{\"type\":" << (int)f.keys[i].type << ",\"shift\":" << (int)f.keys[i].shift << ",\"bits\":" << (int)f.keys[i].bits << "}";
+    o << "],\"accs\":[";
+    for (int i = 0; i < f.n_accs; ++i)
+      o << (i ? "," : "") << "{\"op\":" << (int)f.accs[i].op << ",\"type\":" << (int)f.accs[i].in_type << ",\"track\":" << (int)f.accs[i].track_nn
+        << ",\"has_input\":" << (int)f.accs[i].has_input << "}";
+    o << "]";
+  }
+  // the compile-time description a specialised kernel is built from; @STRUCT@ / @LABEL@ are filled in by the user
+  o << ",\"spec_cpp\":\"" << json_escape(spec_struct_source("@STRUCT@", "@LABEL@", f)) << "\"}";
   return o.str();
 }
 
@@ -984,6 +996,8 @@ qe_status qe_context_create(int32_t device, void *stream, qe_context **out) {
     ctx->c.device = device;
     ctx->c.dev.cus = prop.multiProcessorCount;
     ctx->c.dev.max_lds = (int)prop.sharedMemPerBlock;
+    ctx->c.dev.device = device;
+    ctx->c.dev.jit = jit_default_mode();
     if (stream) {
       ctx->c.stream = (hipStream_t)stream;
     } else {
@@ -999,6 +1013,7 @@ qe_status qe_context_set_flags(qe_context *ctx, uint32_t flags) {
     QE_REQUIRE(ctx, "ctx is null");
     ctx->c.flags = flags;
     ctx->c.dev.specialised = !(flags & QE_FLAG_NO_SPECIALIZED_KERNELS);
+    ctx->c.dev.jit = (flags & QE_FLAG_NO_SPECIALIZED_KERNELS) ? (int)JIT_OFF : (flags & QE_FLAG_JIT_SYNC) ? (int)JIT_SYNC : jit_default_mode();
   });
 }
 
@@ -1404,20 +1419,58 @@ qe_status qe_generate_column(qe_context *ctx, int32_t kind, uint64_t seed, int64
   });
 }
 
+static void lowering_arguments(const int32_t *col_types, const uint8_t *col_nullable, int32_t n_cols, const qe_expr *const *exprs,
+                               int32_t n_exprs, const qe_expr *const *group_exprs, int32_t n_group_exprs,
+                               const qe_agg_expr *const *agg_exprs, int32_t n_agg_exprs, Schema &schema, std::vector<ExprPtr> &outs,
+                               std::vector<ExprPtr> &groups, std::vector<AggExpr> &aggs) {
+  QE_REQUIRE((col_types || n_cols == 0) && n_cols >= 0 && n_exprs >= 0 && n_group_exprs >= 0 && n_agg_exprs >= 0, "bad arguments");
+  for (int i = 0; i < n_cols; ++i) schema.push_back(ColInfo{col_types[i], col_nullable ? col_nullable[i] != 0 : false});
+  for (int i = 0; i < n_exprs; ++i) outs.push_back(exprs[i]->e);
+  for (int i = 0; i < n_group_exprs; ++i) groups.push_back(group_exprs[i]->e);
+  for (int i = 0; i < n_agg_exprs; ++i) aggs.push_back(agg_exprs[i]->a);
+}
+
 qe_status qe_lowering_describe(const int32_t *col_types, const uint8_t *col_nullable, int32_t n_cols, uint32_t flags,
                                const qe_expr *predicate, const qe_expr *const *exprs, int32_t n_exprs,
                                const qe_expr *const *group_exprs, int32_t n_group_exprs, const qe_agg_expr *const *agg_exprs,
                                int32_t n_agg_exprs, int32_t mode, char *buf, int64_t buf_len, int64_t *needed) {
   return guarded([&] {
-    QE_REQUIRE((col_types || n_cols == 0) && n_cols >= 0 && n_exprs >= 0 && n_group_exprs >= 0 && n_agg_exprs >= 0, "bad arguments");
     Schema schema;
-    for (int i = 0; i < n_cols; ++i) schema.push_back(ColInfo{col_types[i], col_nullable ? col_nullable[i] != 0 : false});
     std::vector<ExprPtr> outs, groups;
     std::vector<AggExpr> aggs;
-    for (int i = 0; i < n_exprs; ++i) outs.push_back(exprs[i]->e);
-    for (int i = 0; i < n_group_exprs; ++i) groups.push_back(group_exprs[i]->e);
-    for (int i = 0; i < n_agg_exprs; ++i) aggs.push_back(agg_exprs[i]->a);
-    write_string(describe_lowering(schema, flags, predicate ? predicate->e : nullptr, outs, groups, aggs, mode), buf, buf_len, needed);
+    lowering_arguments(col_types, col_nullable, n_cols, exprs, n_exprs, group_exprs, n_group_exprs, agg_exprs, n_agg_exprs, schema, outs,
+                       groups, aggs);
+    std::string json = "{\"launches\":[";
+    bool first = true;
+    for_each_lowered_launch(schema, flags, predicate ? predicate->e : nullptr, outs, groups, aggs, mode, [&](JitKind kind, const SpecFields &f) {
+      json += (first ? "" : ",") + describe_launch(kind, f);
+      first = false;
+    });
+    json += "]}";
+    write_string(json, buf, buf_len, needed);
+  });
+}
+
+qe_status qe_lowering_compile(const int32_t *col_types, const uint8_t *col_nullable, int32_t n_cols, uint32_t flags,
+                              const qe_expr *predicate, const qe_expr *const *exprs, int32_t n_exprs,
+                              const qe_expr *const *group_exprs, int32_t n_group_exprs, const qe_agg_expr *const *agg_exprs,
+                              int32_t n_agg_exprs, int32_t mode, int32_t *n_kernels, int64_t *code_bytes) {
+  return guarded([&] {
+    QE_REQUIRE(n_kernels && code_bytes, "bad arguments");
+    *n_kernels = 0;
+    *code_bytes = 0;
+    Schema schema;
+    std::vector<ExprPtr> outs, groups;
+    std::vector<AggExpr> aggs;
+    lowering_arguments(col_types, col_nullable, n_cols, exprs, n_exprs, group_exprs, n_group_exprs, agg_exprs, n_agg_exprs, schema, outs,
+                       groups, aggs);
+    for_each_lowered_launch(schema, flags, predicate ? predicate->e : nullptr, outs, groups, aggs, mode, [&](JitKind kind, const SpecFields &f) {
+      size_t n = jit_compile_only(kind, f);
+      if (n) {
+        *n_kernels += 1;
+        *code_bytes += (int64_t)n;
+      }
+    });
   });
 }
 

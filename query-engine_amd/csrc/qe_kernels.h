@@ -11,6 +11,9 @@ struct DeviceInfo {
   int cus;          // compute units
   int max_lds;      // bytes of LDS one workgroup may use
   bool specialised = true;  // use a kernel built for the launch's exact shape when there is one
+  int device = 0;
+  int jit = 0;               // JitMode: compile such a kernel at run time when none was built ahead
+  int64_t jit_min_rows = 1 << 22;  // ... for batches of at least this many rows (background mode)
 };
 
 // Unfiltered projection: every expression of `args` evaluated for every row.

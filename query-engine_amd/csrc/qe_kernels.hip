@@ -18,6 +18,8 @@
 #include <cstdlib>
 
 #include "qe_device.h"
+#include "qe_jit.h"
+#include "qe_kernels.h"
 
 namespace qe {
 
@@ -434,6 +436,10 @@ static int tuned(const char *env, int dflt) {
 static int project_blocks_per_cu() { static int v = tuned("QE_PROJECT_BLOCKS_PER_CU", 2); return v; }
 static int filter_blocks_per_cu() { static int v = tuned("QE_FILTER_BLOCKS_PER_CU", 8); return v; }
 
+static bool jit_wanted(const DeviceInfo &dev, int64_t n_rows) {
+  return dev.specialised && dev.jit != JIT_OFF && (dev.jit == JIT_SYNC || n_rows >= dev.jit_min_rows);
+}
+
 static int grid_for(int64_t work_items, int per_block, int max_blocks) {
   int64_t b = (work_items + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -446,6 +452,9 @@ hipError_t launch_project(const ProjectArgs &args, const DeviceInfo &dev, hipStr
   int grid = grid_for(args.n_rows, VM_BLOCK_ROWS, dev.cus * project_blocks_per_cu());
   hipError_t err;
   if (dev.specialised && static_launch_project(args, grid, stream, &err, kernel_name)) return err;
+  if (jit_wanted(dev, args.n_rows) &&
+      jit_launch(JIT_PROJECT, spec_fields(args), &args, dev.jit, dev.device, grid, VM_BLOCK_THREADS, 0, stream, &err, kernel_name))
+    return err;
   if (program_needs_full(args.prog))
     hipLaunchKernelGGL(qe_project_kernel<true>, dim3(grid), dim3(VM_BLOCK_THREADS), 0, stream, args);
   else
@@ -467,6 +476,16 @@ hipError_t launch_filter(const FilterArgs &args, const DeviceInfo &dev, hipStrea
   int grid = grid_for(args.n_tiles, 1, dev.cus * filter_blocks_per_cu());
   hipError_t err;
   if (dev.specialised && static_launch_filter(args, dev.cus, stream, &err, kernel_name)) return err;
+  if (jit_wanted(dev, args.n_rows)) {
+    // geometry of the specialised filter kernels: bigger tiles, one workgroup per compute unit
+    FilterArgs b = args;
+    const int tile = filter_static_tile_rows((int)args.prog.cache_n);
+    b.n_tiles = (args.n_rows + tile - 1) / tile;
+    const unsigned g = (unsigned)(b.n_tiles < dev.cus ? b.n_tiles : dev.cus);
+    if (jit_launch(JIT_FILTER, spec_fields(b), &b, dev.jit, dev.device, g, filter_static_waves((int)args.prog.cache_n) * 64, 0, stream, &err,
+                   kernel_name))
+      return err;
+  }
   if (program_needs_full(args.prog))
     hipLaunchKernelGGL(qe_filter_kernel<true>, dim3(grid), dim3(VM_BLOCK_THREADS), 0, stream, args);
   else
@@ -508,6 +527,9 @@ hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStrea
   int grid = grid_for(args.n_rows, VM_BLOCK_ROWS, dev.cus * per_cu);
   hipError_t err;
   if (dev.specialised && static_launch_aggregate(args, grid, lds, stream, &err, kernel_name)) return err;
+  if (jit_wanted(dev, args.n_rows) &&
+      jit_launch(JIT_AGGREGATE, spec_fields(args), &args, dev.jit, dev.device, grid, VM_BLOCK_THREADS, lds, stream, &err, kernel_name))
+    return err;
   if (program_needs_full(args.prog))
     hipLaunchKernelGGL(qe_aggregate_kernel<true>, dim3(grid), dim3(VM_BLOCK_THREADS), lds, stream, args);
   else

@@ -25,7 +25,7 @@ inline void sig_program(const VmProgram &P, std::vector<uint32_t> &s) {
   s.push_back((uint32_t)n);
   for (int i = 0; i < n; ++i) s.push_back(P.insn[i]);
   s.push_back(P.cache_n);
-  for (uint32_t i = 0; i < P.cache_n; ++i) s.push_back(P.cache_kind[i]);
+  for (uint32_t i = 0; i < P.cache_n; ++i) s.push_back(P.cache_kind[i] | (P.cols[P.cache_col[i]].validity ? 1u << 8 : 0u));
 }
 
 inline void sig_outs(const VmOut *outs, int n, std::vector<uint32_t> &s) {
@@ -64,11 +64,11 @@ inline std::vector<uint32_t> signature(const AggArgs &A) {
   return s;
 }
 
-// A specialised kernel leaves out validity handling: it only serves launches whose cached
-// columns carry no validity bitmap.
-inline bool cached_columns_all_valid(const VmProgram &P) {
-  for (uint32_t i = 0; i < P.cache_n; ++i)
-    if (P.cols[P.cache_col[i]].validity) return false;
+// Can a launch be served by a shape-specialised kernel at all?  Those kernels implement every
+// instruction except the utf8 comparisons.
+inline bool program_is_specialisable(const VmProgram &P) {
+  for (int i = 0; i < VM_MAX_INSN; ++i)
+    if (!vm_op_specialisable(P.insn[i] & 0xffu)) return false;
   return true;
 }
 

@@ -9,7 +9,7 @@
 
 namespace qe {
 
-template <uint32_t KIND>
+template <uint32_t KIND, bool NULLABLE>
 __device__ __forceinline__ void cache_load_static(const VmCol &col, const RowCtx &c, uint64_t (&v)[VM_R], uint32_t &valid) {
   const int64_t r0 = c.row0 + 2 * (int64_t)c.lane;
   const int64_t r1 = r0 + 128;
@@ -44,14 +44,16 @@ __device__ __forceinline__ void cache_load_static(const VmCol &col, const RowCtx
 #pragma unroll
     for (int j = 0; j < VM_R; ++j) v[j] = (bits >> j) & 1u;
   }
-  valid = 0xFu;  // a Spec only serves columns without a validity bitmap
+  valid = 0xFu;
+  if constexpr (NULLABLE) valid = load_bits4(col.validity, c);
 }
 
 // Loads the cache slots named by MASK (a compile-time constant), decoded, all loads in flight.
 template <class Spec, uint32_t MASK, int I>
 __device__ __forceinline__ void cache_fill_static(const VmProgram &P, const RowCtx &c, ColCache &K) {
   if constexpr (I < Spec::cache_n) {
-    if constexpr ((MASK >> I) & 1u) cache_load_static<Spec::cache_kind[I]>(P.cols[P.cache_col[I]], c, K.v[I], K.valid[I]);
+    if constexpr ((MASK >> I) & 1u)
+      cache_load_static<Spec::cache_kind[I], Spec::cache_nullable[I] != 0>(P.cols[P.cache_col[I]], c, K.v[I], K.valid[I]);
     cache_fill_static<Spec, MASK, I + 1>(P, c, K);
   }
 }
@@ -68,10 +70,38 @@ __device__ __forceinline__ void cache_copy_static(ColCache &dst, const ColCache 
   }
 }
 
+// Integer division / remainder with the null rules of the interpreter (x/0, x%0 and MIN/-1 give
+// null).  Rolled over the four rows: a 64-bit division is long, four copies of it are not worth
+// their instruction-cache space.
+template <bool W32, bool WANT_MOD>
+__device__ __forceinline__ void static_int_divide(Slot &a, Slot &b) {
+  const int64_t tmin = W32 ? (int64_t)INT32_MIN : INT64_MIN;
+  uint32_t valid = a.valid & b.valid;
+#pragma unroll 1
+  for (int it = 0; it < VM_R; ++it) {
+    int64_t x = (int64_t)a.v[0], y = (int64_t)b.v[0];
+    int64_t r = 0;
+    if (y == 0 || (x == tmin && y == -1)) {
+      valid &= ~1u;
+    } else {
+      int64_t q = x / y;
+      r = WANT_MOD ? x - q * y : q;
+    }
+    a.v[0] = (uint64_t)r;
+    QE_ROT4(a.v);
+    QE_ROT4(b.v);
+    valid = rot4(valid);
+  }
+  a.valid = valid;
+}
+
+// The code of one expression, unrolled at compile time: instruction PC, then PC + 1, ... up to
+// OP_END.  Every stack slot and cache entry is named by a constant.
 template <class Spec, int PC>
-__device__ __forceinline__ void eval_static(const VmProgram &P, const ColCache &K, Slot (&S)[VM_MAX_DEPTH]) {
+__device__ __forceinline__ void eval_static(const VmProgram &P, const RowCtx &c, const ColCache &K, Slot (&S)[VM_MAX_DEPTH]) {
   constexpr uint32_t ins = Spec::code[PC];
   constexpr uint32_t op = ins & 0xffu, d = (ins >> 8) & 0xfu, arg = ins >> 12;
+  static_assert(vm_op_specialisable(op), "utf8 comparisons stay with the interpreter kernels");
   if constexpr (op != OP_END) {
     if constexpr (op == OP_PUSH_LIT) {
       const uint64_t l = P.lits[arg];
@@ -83,11 +113,40 @@ __device__ __forceinline__ void eval_static(const VmProgram &P, const ColCache &
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) S[d].v[j] = K.v[arg][j];
       S[d].valid = K.valid[arg];
+    } else if constexpr (op == OP_PUSH_COL64 || op == OP_PUSH_COL32 || op == OP_PUSH_COLBOOL) {
+      // a column beyond the cache: loaded where it is used
+      const VmCol &col = P.cols[arg];
+      constexpr uint32_t kind = op == OP_PUSH_COL64 ? CK_64 : op == OP_PUSH_COL32 ? CK_32 : CK_BOOL;
+      cache_load_static<kind, false>(col, c, S[d].v, S[d].valid);
+      if (col.validity) S[d].valid = load_bits4(col.validity, c);
+    } else if constexpr (op == OP_PUSH_ROWID) {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) S[d].v[j] = (uint64_t)(c.row0 + (j >> 1) * 128 + 2 * (int64_t)c.lane + (j & 1));
+      S[d].valid = 0xFu;
+    } else if constexpr (op == OP_SWAP) {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) {
+        const uint64_t t = S[d - 2].v[j];
+        S[d - 2].v[j] = S[d - 1].v[j];
+        S[d - 1].v[j] = t;
+      }
+      const uint32_t tv = S[d - 2].valid;
+      S[d - 2].valid = S[d - 1].valid;
+      S[d - 1].valid = tv;
+    } else if constexpr (op == OP_I64_TO_F64) {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) S[d - 1].v[j] = d2u((double)(int64_t)S[d - 1].v[j]);
+    } else if constexpr (op == OP_DIV_F64) {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) S[d - 2].v[j] = d2u(u2d(S[d - 2].v[j]) / u2d(S[d - 1].v[j]));
+      S[d - 2].valid &= S[d - 1].valid;
+    } else if constexpr (op == OP_DIV_I32 || op == OP_MOD_I32 || op == OP_DIV_I64 || op == OP_MOD_I64) {
+      static_int_divide<op == OP_DIV_I32 || op == OP_MOD_I32, op == OP_MOD_I32 || op == OP_MOD_I64>(S[d - 2], S[d - 1]);
     } else {
-      static_assert(op_is_fast_binary(op), "a Spec may only hold cached pushes, literals and the fast binaries");
+      static_assert(op_is_fast_binary(op), "unhandled instruction");
       vm_binary_fast(op, S[d - 2], S[d - 1]);
     }
-    eval_static<Spec, PC + 1>(P, K, S);
+    eval_static<Spec, PC + 1>(P, c, K, S);
   }
 }
 
@@ -96,10 +155,10 @@ template <class Spec, int E>
 __device__ __forceinline__ void project_outs_static(const ProjectArgs &A, const RowCtx &c, const ColCache &K) {
   if constexpr (E < Spec::n_outs) {
     Slot S[VM_MAX_DEPTH];
-    eval_static<Spec, Spec::out_pc[E]>(A.prog, K, S);
+    eval_static<Spec, Spec::out_pc[E]>(A.prog, c, K, S);
     VmOut o = A.outs[E];
     o.type = (uint8_t)Spec::out_type[E];
-    o.validity = nullptr;
+    if constexpr (Spec::out_nullable[E] == 0) o.validity = nullptr;
     store_dense(o, c, S[0]);
     project_outs_static<Spec, E + 1>(A, c, K);
   }
@@ -126,16 +185,16 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_project_static(const P
 
 // ------------------------------------------------------------------- filter
 template <class Spec, int E>
-__device__ __forceinline__ void filter_outs_static(const FilterArgs &A, const ColCache &K, unsigned long long obase, uint32_t sel,
-                                                   const uint32_t (&rank)[VM_R]) {
+__device__ __forceinline__ void filter_outs_static(const FilterArgs &A, const RowCtx &c, const ColCache &K, unsigned long long obase,
+                                                   uint32_t sel, const uint32_t (&rank)[VM_R]) {
   if constexpr (E < Spec::n_outs) {
     Slot S[VM_MAX_DEPTH];
-    eval_static<Spec, Spec::out_pc[E]>(A.prog, K, S);
+    eval_static<Spec, Spec::out_pc[E]>(A.prog, c, K, S);
     VmOut o = A.outs[E];
     o.type = (uint8_t)Spec::out_type[E];
-    o.validity = nullptr;
+    if constexpr (Spec::out_nullable[E] == 0) o.validity = nullptr;
     store_compact(o, obase, sel, rank, S[0]);
-    filter_outs_static<Spec, E + 1>(A, K, obase, sel, rank);
+    filter_outs_static<Spec, E + 1>(A, c, K, obase, sel, rank);
   }
 }
 
@@ -148,8 +207,8 @@ __device__ __forceinline__ void filter_outs_static(const FilterArgs &A, const Co
 // up to three cached columns; wider shapes use 512 threads (256 registers) and more steps.
 template <class Spec>
 struct FilterGeometry {
-  static constexpr int WAVES = Spec::cache_n <= 3 ? 16 : 8;
-  static constexpr int STEPS = Spec::cache_n <= 3 ? 2 : Spec::cache_n <= 5 ? 4 : 3;
+  static constexpr int WAVES = filter_static_waves(Spec::cache_n);
+  static constexpr int STEPS = filter_static_steps(Spec::cache_n);
   static constexpr int STEP_ROWS = WAVES * VM_WAVE_ROWS;
   static constexpr int TILE_ROWS = STEPS * STEP_ROWS;
 };
@@ -192,7 +251,7 @@ __global__ __launch_bounds__(FilterGeometry<Spec>::WAVES * 64, 1) void qe_filter
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       Slot S[VM_MAX_DEPTH];
-      eval_static<Spec, Spec::pred_pc>(A.prog, K[s], S);
+      eval_static<Spec, Spec::pred_pc>(A.prog, c[s], K[s], S);
       sel[s] = c[s].active & S[0].valid & bool_bits(S[0]);
       const uint32_t cnt = popc_sel(sel[s]);
       if (lane == 0) s_cnt[s * WAVES + wave] = cnt;
@@ -222,7 +281,7 @@ __global__ __launch_bounds__(FilterGeometry<Spec>::WAVES * 64, 1) void qe_filter
       if (__ballot(sel[s] != 0) == 0) continue;
       uint32_t rank[VM_R];
       rank_rows(sel[s], rank);
-      filter_outs_static<Spec, 0>(A, K[s], base + pref[s], sel[s], rank);
+      filter_outs_static<Spec, 0>(A, c[s], K[s], base + pref[s], sel[s], rank);
     }
   }
 }
@@ -392,7 +451,7 @@ __device__ __forceinline__ void agg_tasks_static(const AggArgs &A, const LdsTabl
     S[0].valid = 0xFu;
 #pragma unroll
     for (int j = 0; j < VM_R; ++j) S[0].v[j] = 1;
-    if constexpr (Spec::task_eval[T] != 0) eval_static<Spec, Spec::task_pc[T]>(A.prog, K, S);
+    if constexpr (Spec::task_eval[T] != 0) eval_static<Spec, Spec::task_pc[T]>(A.prog, c, K, S);
     if constexpr (role == ROLE_PRED) {
       c.active &= S[0].valid & bool_bits(S[0]);
       if (__ballot(c.active != 0) == 0) return;  // nothing of this wave-step survives the filter

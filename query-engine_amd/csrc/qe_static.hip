@@ -4,6 +4,7 @@
 // disagree with what the host would hand the interpreter for the same plan.
 #include <cstring>
 
+#include "qe_kernels.h"
 #include "qe_signature.h"
 #include "qe_static.h"
 #include "qe_static_specs.h"
@@ -56,7 +57,6 @@ const Entry *find(const std::vector<uint32_t> &sig) {
 }  // namespace
 
 bool static_launch_project(const ProjectArgs &args, int grid, hipStream_t stream, hipError_t *err, const char **kernel_name) {
-  if (!cached_columns_all_valid(args.prog)) return false;
   const Entry *e = find(signature(args));
   if (!e || !e->project) return false;
   e->project(args, grid, stream);
@@ -66,7 +66,6 @@ bool static_launch_project(const ProjectArgs &args, int grid, hipStream_t stream
 }
 
 bool static_launch_filter(const FilterArgs &args, int cus, hipStream_t stream, hipError_t *err, const char **kernel_name) {
-  if (!cached_columns_all_valid(args.prog)) return false;
   const Entry *e = find(signature(args));
   if (!e || !e->filter) return false;
   e->filter(args, cus, stream);
@@ -77,7 +76,6 @@ bool static_launch_filter(const FilterArgs &args, int cus, hipStream_t stream, h
 
 bool static_launch_aggregate(const AggArgs &args, int grid, size_t lds_bytes, hipStream_t stream, hipError_t *err,
                              const char **kernel_name) {
-  if (!cached_columns_all_valid(args.prog)) return false;
   const Entry *e = find(signature(args));
   if (!e || !e->aggregate) return false;
   e->aggregate(args, grid, lds_bytes, stream);

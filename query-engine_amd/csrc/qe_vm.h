@@ -57,6 +57,9 @@ enum VmOp : uint32_t {
   OP_COUNT_
 };
 
+// Instructions the shape-specialised kernels implement: everything except the utf8 comparisons.
+constexpr bool vm_op_specialisable(uint32_t op) { return op < OP_COUNT_ && !(op >= OP_UTF8_EQ_LIT && op <= OP_UTF8_NE_COL); }
+
 inline uint32_t vm_insn(uint32_t op, uint32_t depth, uint32_t arg) { return op | (depth << 8) | (arg << 12); }
 
 // Element types of a stack slot / an output column.
@@ -108,6 +111,13 @@ struct FilterScratch {
   unsigned long long pad[5];
   // followed by unsigned long long status[n_tiles]
 };
+
+// Tile geometry of the shape-specialised filter kernels, a function of the number of cached
+// columns (registers per lane): waves per workgroup, steps per tile.  Host and device use this
+// one definition.
+constexpr int filter_static_waves(int cache_n) { return cache_n <= 3 ? 16 : 8; }
+constexpr int filter_static_steps(int cache_n) { return cache_n <= 3 ? 2 : cache_n <= 5 ? 4 : 3; }
+constexpr int filter_static_tile_rows(int cache_n) { return filter_static_steps(cache_n) * filter_static_waves(cache_n) * VM_WAVE_ROWS; }
 
 struct FilterArgs {
   VmProgram prog;

@@ -1,0 +1,87 @@
+"""Kernels compiled at run time for launch shapes that have no kernel built ahead of time: same
+parity bar as the other paths, and the launch profile must show that the compiled kernel ran."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from test_gpu_parity import ALL_AGGS_F64, C, EXPRS, agg_columns, make_columns, mk, rng, run_agg, run_both
+from util import assert_column_equal, gpu_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def jit_ctx(qe, ctx):
+    ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_JIT_SYNC)
+    ctx.profile(True)
+    ctx.profile_read()
+    yield ctx
+    ctx.profile(False)
+    ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP)
+
+
+def jit_kernels(ctx):
+    return [k for k in ctx.profile_read() if "_jit<" in k]
+
+
+def test_expressions_compiled(qe, jit_ctx):
+    """Every expression of the parity list (nulls, NaN, division by zero, MIN / -1, deep trees) through a
+    compiled projection kernel, at a size with a ragged tail."""
+    n = 5000 + 37
+    cols = make_columns(n)
+    chunk = orc.Chunk(cols)
+    batch = gpu_batch(qe, jit_ctx, cols)
+    for spec in EXPRS:
+        want = mk(orc, spec).evaluate(chunk)
+        got = mk(qe, spec).evaluate(batch)
+        assert_column_equal(got.array.columns()[0], want.array, what=f"jit {spec}")
+    assert len(jit_kernels(jit_ctx)) >= len(EXPRS) - 4  # shapes that coincide share a kernel
+
+
+def test_filter_and_aggregate_compiled(qe, jit_ctx):
+    cols = make_columns(20_000, seed=3)
+    parts = [make_columns(n, seed=s) for n, s in ((5000, 1), (1, 2), (9000, 3))]
+
+    def chain(m, scan):
+        s1 = m.SelectionExec([scan], mk(m, ("gt", C(5), ("f64", 0.5))))
+        p1 = m.ProjectionExec([s1], [mk(m, ("add", C(4), ("mul", C(5), C(5)))), mk(m, C(1)), mk(m, C(6)), mk(m, C(3))])
+        s2 = m.SelectionExec([p1], mk(m, ("lt", C(1), ("i32", 25))))
+        return m.ProjectionExec([s2], [mk(m, ("mul", C(0), ("f64", 2.0))), mk(m, C(2)), mk(m, ("add", C(3), ("i64", 1)))])
+    run_both(qe, jit_ctx, parts, chain, what="jit selection/projection chain")
+    run_both(qe, jit_ctx, [cols], lambda m, scan: m.SelectionExec([scan], mk(m, ("gt", C(4), ("f64", 0.0)))), what="jit null predicate, all columns")
+    assert any(k.startswith("qe_filter_jit<") for k in jit_kernels(jit_ctx))
+    for n, n_keys in ((1, 1), (5000, 10), (70_000, 3000)):
+        run_agg(qe, jit_ctx, [agg_columns(n, n_keys, seed=n + n_keys)], [C(0)], ALL_AGGS_F64, what=f"jit agg n={n} keys={n_keys}")
+    acols = agg_columns(30_000, 40, seed=11, key_dtype=np.int32)
+    run_agg(qe, jit_ctx, [acols], [C(0), C(1)], ALL_AGGS_F64, what="jit two int32 keys")
+    run_agg(qe, jit_ctx, [acols], [("mod", C(1), ("i32", 2))], [("sum", ("add", C(2), ("mul", C(5), C(5)))), ("max", ("mul", C(4), C(1))), ("avg", C(3))],
+            pred=("gt", C(5), ("f64", 0.5)), what="jit computed key, filter, int avg")
+    assert any(k.startswith("qe_aggregate_jit<") for k in jit_kernels(jit_ctx))
+
+
+def test_background_compilation(qe, ctx):
+    """Default mode: the first launches of a new shape run on the general kernel while the compiler works
+    on another thread; later launches pick the compiled kernel up.  Results agree."""
+    n = 5_000_000  # above the row threshold of background compilation
+    r = rng(4)
+    a, b = r.uniform(-1, 1, n), r.uniform(0, 1, n)
+    batch = gpu_batch(qe, ctx, [orc.Array(orc.FLOAT64, a), orc.Array(orc.FLOAT64, b)])
+    expr = lambda: qe.SubExpression(qe.MulExpression(qe.ColumnExpression(0), qe.LiteralFloatExpression(3.25)), qe.ColumnExpression(1))
+    want = a * 3.25 - b
+    ctx.profile(True)
+    try:
+        ctx.profile_read()
+        first = expr().evaluate(batch).array.columns()[0].values
+        names = set(ctx.profile_read())
+        assert np.array_equal(first, want)
+        deadline = time.time() + 60
+        while not any("_jit<" in k for k in names) and time.time() < deadline:
+            time.sleep(0.2)
+            got = expr().evaluate(batch).array.columns()[0].values
+            names = set(ctx.profile_read())
+        assert any(k.startswith("qe_project_jit<") for k in names), names
+        assert np.array_equal(got, want)
+    finally:
+        ctx.profile(False)

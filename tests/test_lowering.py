@@ -54,3 +54,25 @@ def test_generated_specs_are_current(tmp_path):
     gen.OUT = str(tmp_path / "specs.h")
     gen.main()
     assert open(gen.OUT).read() == committed, "run tools/gen_static_specs.py and rebuild"
+
+
+def test_runtime_compilation_offline(qe):
+    """The run-time compiler builds a kernel for shapes that were not built ahead of time (no GPU needed):
+    nullable inputs, operand swaps, division, casts, more columns than the cache holds."""
+    C, F, I = qe.ColumnExpression, qe.LiteralFloatExpression, qe.LiteralIntegerExpression
+    i32, i64, f64, boolean, utf8 = qe.TYPE_INT32, qe.TYPE_INT64, qe.TYPE_FLOAT64, qe.TYPE_BOOLEAN, qe.TYPE_UTF8
+    nk, nb = qe.compile_lowering([i64, f64, f64, f64], [False, True, False, True], predicate=qe.LtExpression(C(3), F(0.25)),
+                                 exprs=[C(0), qe.SubExpression(C(1), qe.MulExpression(C(2), C(3)))], group_exprs=[C(0)],
+                                 agg_exprs=[qe.SumExpression(C(1)), qe.MinExpression(C(1)), qe.CountExpression(C(1)), qe.AvgExpression(C(1))])
+    assert nk == 1 and nb > 4096
+    nk, _ = qe.compile_lowering([i32, f64, boolean], [True, False, False], predicate=qe.AndExpression(C(2), qe.GtExpression(C(0), I(3))),
+                                exprs=[qe.AddExpression(C(0), C(0)), qe.MulExpression(C(1), F(2.0)), C(2)])
+    assert nk == 1
+    nk, _ = qe.compile_lowering([i32, f64], exprs=[qe.DivExpression(C(1), F(2.0)), qe.ModExpression(C(0), I(7)), qe.DivExpression(I(100), C(0))])
+    assert nk == 1
+    nk, _ = qe.compile_lowering([i32] * 9, exprs=[qe.AddExpression(C(i), C(8 - i)) for i in range(4)])  # 8 columns, 6 cached
+    assert nk == 1
+    # utf8 comparisons run on the general kernels only
+    assert qe.compile_lowering([utf8, i32], exprs=[qe.EqExpression(C(0), C(0))]) == (0, 0)
+    d = qe.describe_lowering([utf8, i32], exprs=[qe.EqExpression(C(0), C(0))])
+    assert d["launches"][0]["specialisable"] == 0
