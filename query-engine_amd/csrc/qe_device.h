@@ -724,6 +724,7 @@ __device__ __forceinline__ uint64_t ord_inverse(uint64_t img, uint32_t type) {
 __device__ __forceinline__ uint64_t acc_identity(uint32_t op) { return op == ACC_MIN ? ~0ull : 0ull; }
 
 constexpr int32_t SLOT_NONE = INT32_MIN;
+constexpr int32_t SLOT_LDS_MISS = -1;  // transient: no room in the LDS table, the row needs another home
 constexpr int LDS_MAX_PROBE = 8;
 
 struct LdsTable {
@@ -801,30 +802,65 @@ __device__ __forceinline__ int32_t lds_find_or_claim(const LdsTable &L, uint64_t
   return -1;
 }
 
-// The hot case of the lookup: the key already sits in its home slot.  One LDS read, no loop;
-// the reads of a lane's four rows are issued together.  SLOT_PENDING = not found this way.
+// The hot case of the lookup: the key already sits in, or right after, its home slot.  Read-only
+// probes of the lane's four rows, issued together probe by probe (four independent LDS reads in
+// flight instead of a serial chain per row).  Outcome per row:
+//   slot >= 0      found
+//   SLOT_PENDING   an empty slot came first: the key is not in the table and may be claimable,
+//                  or FAST_PROBES slots held other keys: the full lookup decides
+//   SLOT_LDS_MISS  (only when `table_full`) the key is not among the first FAST_PROBES slots or an
+//                  empty slot came first: nothing can be claimed any more, so this is final
 constexpr int32_t SLOT_PENDING = INT32_MIN + 1;
-__device__ __forceinline__ void lds_probe_home(const LdsTable &L, const uint64_t (&key)[VM_R], uint32_t rows, int32_t (&slot)[VM_R]) {
+constexpr int FAST_PROBES = 3;
+__device__ __forceinline__ void lds_probe_fast(const LdsTable &L, const uint64_t (&key)[VM_R], uint32_t rows, bool table_full,
+                                               int32_t (&slot)[VM_R]) {
   uint32_t h[VM_R];
-  unsigned long long cur[VM_R];
+  uint32_t open = rows;  // rows still looking
 #pragma unroll
   for (int j = 0; j < VM_R; ++j) {
     h[j] = hash32(key[j]) & (L.cap - 1);
-    cur[j] = AGG_EMPTY_KEY;
-    if ((rows >> j) & 1u) cur[j] = *(volatile unsigned long long *)&L.keys[h[j]];
+    slot[j] = ((rows >> j) & 1u) ? (table_full ? SLOT_LDS_MISS : SLOT_PENDING) : SLOT_NONE;
+    // the key equal to the empty marker lives in the reserved slot: full lookup
+    if (((rows >> j) & 1u) && key[j] == AGG_EMPTY_KEY) {
+      slot[j] = SLOT_PENDING;
+      open &= ~(1u << j);
+    }
   }
 #pragma unroll
-  for (int j = 0; j < VM_R; ++j) {
-    slot[j] = SLOT_NONE;
-    if ((rows >> j) & 1u) slot[j] = (cur[j] == key[j] && key[j] != AGG_EMPTY_KEY) ? (int32_t)h[j] : SLOT_PENDING;
+  for (int d = 0; d < FAST_PROBES; ++d) {
+    unsigned long long cur[VM_R];
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) {
+      cur[j] = AGG_EMPTY_KEY;
+      if ((open >> j) & 1u) cur[j] = *(volatile unsigned long long *)&L.keys[(h[j] + d) & (L.cap - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) {
+      if ((open >> j) & 1u) {
+        if (cur[j] == key[j]) {
+          slot[j] = (int32_t)((h[j] + d) & (L.cap - 1));
+          open &= ~(1u << j);
+        } else if (cur[j] == AGG_EMPTY_KEY) {
+          open &= ~(1u << j);  // not in the table; slot[j] already says what that means
+        }
+      }
+    }
+    if (d + 1 < FAST_PROBES && __ballot(open != 0) == 0) break;
   }
 }
 
 __device__ __forceinline__ void acc_apply(unsigned long long *p, uint32_t op, uint64_t v) {
   switch (op) {
     case ACC_SUM_F64: atomicAdd((double *)p, u2d(v)); break;
-    case ACC_MIN: atomicMin(p, (unsigned long long)v); break;
-    case ACC_MAX: atomicMax(p, (unsigned long long)v); break;
+    // min / max: a plain read first.  The stored value only ever moves one way, so a value that
+    // does not beat what a (possibly stale) read returns cannot beat the current one either, and
+    // the atomic is skipped: after the first few rows of a group that is nearly every row.
+    case ACC_MIN:
+      if ((unsigned long long)v < *(volatile unsigned long long *)p) atomicMin(p, (unsigned long long)v);
+      break;
+    case ACC_MAX:
+      if ((unsigned long long)v > *(volatile unsigned long long *)p) atomicMax(p, (unsigned long long)v);
+      break;
     default: atomicAdd(p, (unsigned long long)v); break;  // ACC_SUM_I64, ACC_COUNT
   }
 }
@@ -852,7 +888,6 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
 
 constexpr uint32_t LEADER_MIN_ROWS = 24;
 constexpr int LEADER_TRIES = 2;
-constexpr int32_t SLOT_LDS_MISS = -1;  // transient: the row still needs a global slot
 
 // ------------------------------------------------------------ aggregate sink
 // Shared by the interpreted and the statically specialised aggregate kernels.
@@ -874,14 +909,52 @@ struct AggRows {
   uint32_t rem;        // rows folded one by one
   uint32_t lead_mb;    // rows folded through the wave reduction
   int32_t lead_slot;   // wave-uniform; SLOT_NONE = no dominant key in this wave-step
+  uint32_t spill_mb;   // rows logged for the second phase instead (high-cardinality mode)
+  uint64_t spill_pos;  // log position of the lane's first such row; the others follow
 };
+
+// A wave's cursor into its region of the spill log.
+struct SpillState {
+  unsigned long long *keys;  // nullptr: high-cardinality mode off
+  unsigned long long *vals;
+  uint64_t capacity;
+  uint64_t base;     // first row of this wave's region
+  uint32_t cursor;   // rows logged so far (wave-uniform)
+};
+
+__device__ __forceinline__ SpillState spill_begin(const AggSpill &sp, uint32_t wave_in_block) {
+  SpillState s;
+  s.keys = sp.keys;
+  s.vals = sp.vals;
+  s.capacity = sp.capacity;
+  s.base = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block) * sp.rows_per_wave;
+  s.cursor = 0;
+  return s;
+}
+__device__ __forceinline__ void spill_end(const AggSpill &sp, const SpillState &s, uint32_t wave_in_block, uint32_t lane) {
+  if (sp.keys && lane == 0) sp.counts[blockIdx.x * (blockDim.x >> 6) + wave_in_block] = s.cursor;
+}
+
+// Logs one evaluated accumulator input of the spilled rows to value column `col`.
+__device__ __forceinline__ void spill_values(const SpillState &sp, uint32_t col, const Slot &in, const AggRows &G) {
+  unsigned long long *dst = sp.vals + (uint64_t)col * sp.capacity + G.spill_pos;
+  uint32_t k = 0;
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    if ((G.spill_mb >> j) & 1u) dst[k] = in.v[j];
+    k += (G.spill_mb >> j) & 1u;
+  }
+}
 
 // Finds / claims the group slot of every active row and counts the rows in.
 template <bool TRY_LEADER = true>
-__device__ __forceinline__ void agg_lookup(const LdsTable &L, const AggTable &T, uint32_t active, uint32_t lane, AggRows &G) {
+__device__ __forceinline__ void agg_lookup(const LdsTable &L, const AggTable &T, uint32_t active, uint32_t lane, AggRows &G,
+                                           SpillState &sp) {
   uint32_t rem = active;
+  G.spill_mb = 0;
+  G.spill_pos = 0;
   // ---- a key that dominates the wave-step?  Try the first row of up to two lanes.
-  uint64_t ball = TRY_LEADER ? __ballot(rem != 0) : 0ull;
+  uint64_t ball = (TRY_LEADER && !sp.keys) ? __ballot(rem != 0) : 0ull;
   uint64_t k0 = 0;
   uint32_t lead_cnt = 0, lead_mb = 0;
   int src = 0;
@@ -915,7 +988,10 @@ __device__ __forceinline__ void agg_lookup(const LdsTable &L, const AggTable &T,
     const uint32_t hl = hash32(k0) & (L.cap - 1);
     unsigned long long curl = AGG_EMPTY_KEY;
     if (lead_cnt != 0) curl = *(volatile unsigned long long *)&L.keys[hl];
-    lds_probe_home(L, G.key, rem, G.slot);
+    // once the table has stopped accepting keys a failed probe is final in high-cardinality mode
+    // (the row is logged); otherwise the full lookup may still claim a slot or reach further
+    const bool table_full = sp.keys != nullptr && *(volatile uint32_t *)L.used >= L.limit;
+    lds_probe_fast(L, G.key, rem, table_full, G.slot);
     if (lead_cnt != 0 && (int)lane == src) lsl = (curl == k0 && k0 != AGG_EMPTY_KEY) ? (int32_t)hl : SLOT_PENDING;
   }
   uint32_t pend = 0;
@@ -938,7 +1014,34 @@ __device__ __forceinline__ void agg_lookup(const LdsTable &L, const AggTable &T,
   for (int j = 0; j < VM_R; ++j)
     if (G.slot[j] == SLOT_LDS_MISS) miss |= 1u << j;
   const bool lead_miss = lsl == SLOT_LDS_MISS;
-  if (__ballot(miss != 0 || lead_miss) != 0) {
+  if (sp.keys) {
+    // high-cardinality mode: these rows go to the wave's log, in lane order
+    const uint64_t any = __ballot(miss != 0);
+    if (any != 0) {
+      const uint32_t mine = (uint32_t)__popc(miss);
+      // exclusive prefix of `mine` over the lanes: two ballots per bit of a 3-bit count
+      uint32_t before = 0, total = 0;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const uint64_t m = __ballot(((mine >> b) & 1u) != 0);
+        before += mbcnt64(m) << b;
+        total += (uint32_t)__popcll(m) << b;
+      }
+      G.spill_mb = miss;
+      G.spill_pos = sp.base + sp.cursor + before;
+      uint32_t k = 0;
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) {
+        if ((miss >> j) & 1u) {
+          sp.keys[G.spill_pos + k] = G.key[j];
+          G.slot[j] = SLOT_NONE;
+        }
+        k += (miss >> j) & 1u;
+      }
+      sp.cursor += total;
+      rem &= ~miss;
+    }
+  } else if (__ballot(miss != 0 || lead_miss) != 0) {
 #pragma unroll 1
     for (int it = 0; it <= VM_R; ++it) {
       const bool lead_it = it == 0;

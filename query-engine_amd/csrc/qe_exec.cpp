@@ -524,6 +524,120 @@ static void lower_aggregate(Compiler &comp, const Schema &schema, const ExprPtr 
   args.n_accs = (int)bspec.accs.size();
 }
 
+// ------------------------------------------------------ high-cardinality mode
+// With very many groups most rows miss the workgroups' LDS tables, and one scattered global atomic
+// per row and accumulator is what the kernel then spends its time on.  When the caller's group-count
+// hint says so, those rows are logged instead (AggSpill), partitioned by key hash and aggregated
+// partition by partition in LDS: a few streaming passes over a fraction of the rows.
+constexpr int64_t SPILL_MIN_GROUP_HINT = 1 << 16;
+constexpr int SPILL_MAX_INPUTS = 8;
+
+struct SpillPlan {
+  bool on = false;
+  BufferPtr keys, vals, counts;
+  int waves = 0;
+  uint8_t acc_col[VM_MAX_ACCS];
+};
+
+static bool spill_enabled() {
+  static int v = [] {
+    const char *e = getenv("QE_AGGREGATE_SPILL");
+    return e ? atoi(e) : 1;
+  }();
+  return v != 0;
+}
+
+// Decides on the mode for one launch and, when on, attaches the log buffers to `args`.
+static SpillPlan plan_spill(Context *ctx, const AggSpec &bspec, AggArgs &args, int64_t group_hint) {
+  SpillPlan sp;
+  std::memset(args.spill_col, 0xff, sizeof(args.spill_col));
+  std::memset(sp.acc_col, 0xff, sizeof(sp.acc_col));
+  if (!spill_enabled() || group_hint < SPILL_MIN_GROUP_HINT || args.n_rows >= (1ll << 31) || args.n_accs == 0) return sp;
+  // the log carries values only: every accumulator must read a non-nullable input
+  std::vector<std::string> inputs;
+  for (int i = 0; i < args.n_accs; ++i) {
+    const AccDesc &d = bspec.accs[i];
+    if (!d.input || args.accs[i].track_nn || args.accs[i].op == ACC_COUNT) return sp;
+    std::string key = expr_to_string(d.input) + (d.input->to_f64 ? "#f64" : "");
+    size_t col = 0;
+    while (col < inputs.size() && inputs[col] != key) ++col;
+    if (col == inputs.size()) {
+      if ((int)inputs.size() >= SPILL_MAX_INPUTS) return sp;
+      inputs.push_back(key);
+      args.spill_col[i] = (uint8_t)col;  // the first accumulator with this input logs it
+    }
+    sp.acc_col[i] = (uint8_t)col;
+  }
+  const int grid = aggregate_grid(args, ctx->dev);
+  sp.waves = grid * VM_BLOCK_WAVES;
+  const int64_t nsteps = (args.n_rows + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
+  const int64_t steps_per_wave = (nsteps + sp.waves - 1) / sp.waves;
+  AggSpill &a = args.spill;
+  a.rows_per_wave = (uint32_t)(steps_per_wave * VM_WAVE_ROWS);
+  a.capacity = (uint64_t)sp.waves * a.rows_per_wave;
+  a.n_inputs = (uint32_t)inputs.size();
+  sp.keys = device_buffer(ctx, a.capacity * 8 + 64);
+  sp.vals = device_buffer(ctx, a.capacity * 8 * a.n_inputs + 64);
+  sp.counts = device_buffer(ctx, (size_t)sp.waves * 4 + 64);
+  QE_HIP(hipMemsetAsync(sp.counts->ptr, 0, (size_t)sp.waves * 4, ctx->stream));
+  a.keys = (unsigned long long *)sp.keys->ptr;
+  a.vals = (unsigned long long *)sp.vals->ptr;
+  a.counts = (uint32_t *)sp.counts->ptr;
+  sp.on = true;
+  return sp;
+}
+
+// Second phase: partition the log by key hash, aggregate partition by partition.
+static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &args, int64_t group_hint) {
+  // partitions: up to 1280 distinct keys each, which the LDS table of the second phase (at least 2048
+  // slots, filled to three quarters) holds; fewer partitions mean deeper stages in the move
+  int bits = 6;
+  while (bits < 11 && ((int64_t)1 << bits) * 1280 < group_hint) ++bits;
+  const int blocks = ctx->dev.cus;
+  const size_t cells = spill_cells(bits, blocks);
+  BufferPtr cell_buf = device_buffer(ctx, (cells + 1) * 4 + 64);
+  BufferPtr scan_buf = device_buffer(ctx, scan_scratch_elems((int64_t)cells) * 4 + 64);
+  int32_t *cell = (int32_t *)cell_buf->ptr;
+  unsigned long long *total = ctx->counters + 2;
+  QE_HIP(hipMemsetAsync(total, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  ctx->prof_begin("qe_spill_count_kernel");
+  QE_HIP(launch_spill_partition(args.spill, sp.waves, bits, blocks, false, cell, nullptr, nullptr, total, ctx->stream));
+  ctx->prof_end();
+  QE_HIP(launch_exclusive_scan_i32(cell, (int64_t)cells, (int32_t *)scan_buf->ptr, ctx->stream));
+  QE_HIP(hipMemcpyAsync(ctx->host_counters + 2, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  ctx->sync();
+  const int64_t m = (int64_t)ctx->host_counters[2];
+  if (m == 0) return;
+  BufferPtr out_keys = device_buffer(ctx, (size_t)m * 8 + 64);
+  BufferPtr out_vals = device_buffer(ctx, args.spill.capacity * 8 * args.spill.n_inputs + 64);
+  ctx->prof_begin("qe_spill_move_kernel");
+  QE_HIP(launch_spill_partition(args.spill, sp.waves, bits, blocks, true, cell, (unsigned long long *)out_keys->ptr,
+                                (unsigned long long *)out_vals->ptr, total, ctx->stream));
+  ctx->prof_end();
+  PartArgs pa{};
+  pa.keys = (const unsigned long long *)out_keys->ptr;
+  pa.vals = (const unsigned long long *)out_vals->ptr;
+  pa.capacity = args.spill.capacity;
+  pa.offsets = cell;
+  pa.n_parts = 1 << bits;
+  pa.stride = blocks;
+  pa.total = m;
+  for (int i = 0; i < args.n_accs; ++i) {
+    pa.accs[i] = args.accs[i];
+    pa.acc_col[i] = sp.acc_col[i];
+  }
+  pa.n_accs = args.n_accs;
+  pa.n_inputs = (int)args.spill.n_inputs;
+  pa.table = args.table;
+  pa.lds_cap = partitioned_lds_slots(args.n_accs);
+  pa.lds_limit = pa.lds_cap - pa.lds_cap / 4;
+  pa.ticket = total + 1;
+  ctx->prof_begin("qe_aggregate_partitioned_kernel");
+  QE_HIP(launch_aggregate_partitioned(pa, ctx->dev, ctx->stream));
+  ctx->prof_end();
+  // the buffers go back to the pool on return: any later use is ordered behind these kernels on the stream
+}
+
 struct AggIter : Iter {
   Context *ctx;
   Stream s;
@@ -606,10 +720,12 @@ struct AggIter : Iter {
         args.n_rows = in.rows;
         args.lds_cap = aggregate_lds_slots(args.n_accs, ctx->dev, cap_hint);
         args.lds_limit = args.lds_cap - args.lds_cap / 4;
+        SpillPlan sp = plan_spill(ctx, bspec, args, cap_hint);
         const char *kname = "qe_aggregate_kernel";
         ctx->prof_begin(kname);
         QE_HIP(launch_aggregate(args, ctx->dev, ctx->stream, &kname));
         ctx->prof_end(kname);
+        if (sp.on) aggregate_spilled(ctx, sp, args, cap_hint);
         if (!comp.keepalive.empty()) ctx->sync();
       }
       // empty input: `iter.next().ok_or(Error::EmptyHashmapForAggregate)` (physical_plan/mod.rs:377)

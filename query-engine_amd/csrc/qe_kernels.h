@@ -32,6 +32,17 @@ hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStrea
 // LDS bytes per slot for a given accumulator count, and the slot count chosen.
 uint32_t aggregate_lds_slots(int n_accs, const DeviceInfo &dev, int64_t group_hint);
 
+// High-cardinality mode, second phase (see AggSpill): partition the spill log by key hash
+// (count, scan by the caller, move), then aggregate partition by partition.
+size_t spill_cells(int bits, int blocks);
+hipError_t launch_spill_partition(const AggSpill &sp, int n_segments, int bits, int blocks, bool move, int32_t *cells,
+                                  unsigned long long *out_keys, unsigned long long *out_vals, unsigned long long *total,
+                                  hipStream_t stream);
+uint32_t partitioned_lds_slots(int n_accs);
+hipError_t launch_aggregate_partitioned(const PartArgs &args, const DeviceInfo &dev, hipStream_t stream);
+// Workgroups launch_aggregate will use for these arguments (sizes the per-wave spill regions).
+int aggregate_grid(const AggArgs &args, const DeviceInfo &dev);
+
 // Fill a fresh global group table with the empty key / accumulator identities.
 hipError_t launch_table_init(const AggTable &table, const VmAcc *accs, int n_accs, hipStream_t stream);
 // Compact occupied slots into output columns.

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, FULL ? 2 : 3) void qe_aggregate_k
   const uint32_t task_w = (uint32_t)A.tasks[tl].role | ((uint32_t)A.tasks[tl].idx << 8) | ((uint32_t)A.tasks[tl].has_eval << 16);
   const uint32_t key_w = (uint32_t)A.keys[lane & (VM_MAX_KEYS - 1)].shift | ((uint32_t)A.keys[lane & (VM_MAX_KEYS - 1)].bits << 8);
   const uint32_t acc_w = (uint32_t)A.accs[lane & (VM_MAX_ACCS - 1)].op | ((uint32_t)A.accs[lane & (VM_MAX_ACCS - 1)].in_type << 8) |
-                         ((uint32_t)A.accs[lane & (VM_MAX_ACCS - 1)].track_nn << 16);
+                         ((uint32_t)A.accs[lane & (VM_MAX_ACCS - 1)].track_nn << 16) | ((uint32_t)A.spill_col[lane & (VM_MAX_ACCS - 1)] << 24);
+  SpillState sp = spill_begin(A.spill, wave);
 
   const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
   for (int64_t ws = (int64_t)blockIdx.x * VM_BLOCK_WAVES + wave; ws < nsteps;
@@ -200,14 +201,225 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, FULL ? 2 : 3) void qe_aggregate_k
 #pragma unroll
         for (int j = 0; j < VM_R; ++j) G.key[j] |= (S[0].v[j] & fmask) << sh;
       } else if (role == ROLE_LOOKUP) {
-        agg_lookup(L, A.table, c.active, lane, G);
+        agg_lookup(L, A.table, c.active, lane, G, sp);
       } else {  // ROLE_ACC
         const uint32_t aw = (uint32_t)__builtin_amdgcn_readlane((int)acc_w, (int)idx);
+        if (G.spill_mb != 0 && (aw >> 24) != 0xffu) spill_values(sp, aw >> 24, S[0], G);
         agg_fold(L, A.table, idx, aw & 0xffu, (aw >> 8) & 0xffu, ((aw >> 16) & 0xffu) != 0, S[0], G, lane);
       }
     }
   }
+  spill_end(A.spill, sp, wave, lane);
   agg_flush(L, A.table, A.accs, A.n_accs);
+}
+
+// ------------------------------------------- high-cardinality second phase
+// The spill log is a set of per-wave segments (segment w: rows [w * rows_per_wave, + counts[w])).
+// Phase 2a counts the rows of every partition per workgroup, 2b scans the counts (partition-major,
+// so the scan IS the layout), 2c moves the rows, 2d aggregates one partition at a time in LDS.
+constexpr int PART_THREADS = 1024;
+constexpr int PART_MAX_BITS = 11;
+
+__device__ __forceinline__ uint32_t partition_of(unsigned long long key, int bits) { return (uint32_t)(mix64(key) >> (64 - bits)); }
+
+// MOVE = false: histogram only.  MOVE = true: `cursors` holds the scanned start of every
+// (partition, workgroup) cell; rows are copied to their partition.
+template <bool MOVE>
+__global__ __launch_bounds__(PART_THREADS) void qe_spill_partition_kernel(AggSpill sp, int n_segments, int bits, int32_t *cells,
+                                                                            unsigned long long *out_keys, unsigned long long *out_vals,
+                                                                            unsigned long long *total) {
+  __shared__ uint32_t s_cell[1 << PART_MAX_BITS];
+  const int P = 1 << bits;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) s_cell[p] = MOVE ? (uint32_t)cells[p * gridDim.x + blockIdx.x] : 0u;
+  __syncthreads();
+  unsigned long long mine = 0;
+  for (int seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
+    const uint32_t cnt = sp.counts[seg];
+    const uint64_t base = (uint64_t)seg * sp.rows_per_wave;
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+      const unsigned long long key = sp.keys[base + i];
+      const uint32_t p = partition_of(key, bits);
+      const uint32_t pos = atomicAdd(&s_cell[p], 1u);
+      if (MOVE) {
+        out_keys[pos] = key;
+        for (uint32_t v = 0; v < sp.n_inputs; ++v) out_vals[(uint64_t)v * sp.capacity + pos] = sp.vals[(uint64_t)v * sp.capacity + base + i];
+      }
+    }
+    if (!MOVE && threadIdx.x == 0) mine += cnt;
+  }
+  if (!MOVE) {
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += blockDim.x) cells[p * gridDim.x + blockIdx.x] = (int32_t)s_cell[p];
+    if (threadIdx.x == 0 && mine) atomicAdd(total, mine);
+  }
+}
+
+// The move with LDS staging.  Written one row at a time, every store of the plain kernel above opens
+// a different cache line (partitions x workgroups of them are open at once, far more than L2 holds),
+// and the partial lines are written back again and again.  Here a workgroup collects up to S rows per
+// partition in LDS and writes them as one burst, eight lanes to a burst; rows that find their
+// partition's stage full are written directly (rare: a stage is emptied as soon as it is three
+// quarters full).  The next round's rows are loaded before the current round is staged, so the
+// barriers of a round do not leave the memory pipeline empty.
+// Dynamic LDS: keys[P * S], then vals[n_inputs][P * S].
+constexpr int MOVE_MAX_INPUTS = 8;
+
+__global__ __launch_bounds__(PART_THREADS) void qe_spill_move_staged_kernel(AggSpill sp, int n_segments, int bits, int S, const int32_t *cells,
+                                                                            unsigned long long *out_keys, unsigned long long *out_vals) {
+  extern __shared__ unsigned long long lds_stage[];
+  __shared__ uint32_t s_cur[1 << PART_MAX_BITS];    // next output row of each partition (this workgroup's cell)
+  __shared__ uint32_t s_cnt[1 << PART_MAX_BITS];    // rows offered to the stage since its last flush
+  __shared__ uint32_t s_ready[1 << PART_MAX_BITS];  // partitions to flush in this round
+  __shared__ uint32_t s_nready;
+  const int P = 1 << bits;
+  unsigned long long *st_keys = lds_stage;
+  unsigned long long *st_vals = lds_stage + (size_t)P * S;
+  const uint32_t n_in = sp.n_inputs;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    s_cur[p] = (uint32_t)cells[p * gridDim.x + blockIdx.x];
+    s_cnt[p] = 0;
+  }
+  if (threadIdx.x == 0) s_nready = 0;
+  __syncthreads();
+
+  // Burst writes: a group of eight lanes takes one ready partition.
+  auto flush = [&](uint32_t threshold) {
+    for (int p = threadIdx.x; p < P; p += blockDim.x)
+      if (s_cnt[p] >= threshold && s_cnt[p] != 0) s_ready[atomicAdd(&s_nready, 1u)] = (uint32_t)p;
+    __syncthreads();
+    const uint32_t nready = s_nready;
+    const uint32_t sub = threadIdx.x & 7u;
+    for (uint32_t q = threadIdx.x >> 3; q < nready; q += blockDim.x >> 3) {
+      const uint32_t p = s_ready[q];
+      const uint32_t offered = s_cnt[p];
+      const uint32_t n = offered < (uint32_t)S ? offered : (uint32_t)S;
+      const uint32_t base = s_cur[p];
+      for (uint32_t i = sub; i < n; i += 8) out_keys[base + i] = st_keys[(size_t)p * S + i];
+      for (uint32_t v = 0; v < n_in; ++v)
+        for (uint32_t i = sub; i < n; i += 8) out_vals[(uint64_t)v * sp.capacity + base + i] = st_vals[((size_t)v * P + p) * S + i];
+      if (sub == 0) {  // the group's lanes run in lockstep: everyone has read s_cur / s_cnt above
+        s_cur[p] = base + n;
+        s_cnt[p] = 0;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_nready = 0;
+  };
+
+  // (segment, offset) of the round in flight and of the one being loaded; uniform over the workgroup
+  int seg = blockIdx.x;
+  uint32_t i0 = 0;
+  uint32_t cnt = 0;
+  while (seg < n_segments && (cnt = sp.counts[seg]) == 0) seg += gridDim.x;
+  bool have = false;
+  unsigned long long key = 0, val[MOVE_MAX_INPUTS];
+  auto load_round = [&](int sg, uint32_t off, uint32_t c) {
+    const uint32_t i = off + threadIdx.x;
+    have = sg < n_segments && i < c;
+    if (have) {
+      const uint64_t r = (uint64_t)sg * sp.rows_per_wave + i;
+      key = sp.keys[r];
+#pragma unroll
+      for (int v = 0; v < MOVE_MAX_INPUTS; ++v)
+        if ((uint32_t)v < n_in) val[v] = sp.vals[(uint64_t)v * sp.capacity + r];
+    }
+  };
+  load_round(seg, i0, cnt);
+  const uint32_t flush_at = (uint32_t)(S - S / 4);
+  while (seg < n_segments) {
+    // this round's rows are in registers; advance and start loading the next round's
+    const bool cur_have = have;
+    const unsigned long long cur_key = key;
+    unsigned long long cur_val[MOVE_MAX_INPUTS];
+#pragma unroll
+    for (int v = 0; v < MOVE_MAX_INPUTS; ++v) cur_val[v] = val[v];
+    i0 += blockDim.x;
+    if (i0 >= cnt) {
+      i0 = 0;
+      seg += gridDim.x;
+      while (seg < n_segments && (cnt = sp.counts[seg]) == 0) seg += gridDim.x;
+    }
+    load_round(seg, i0, cnt);
+    if (cur_have) {
+      const uint32_t p = partition_of(cur_key, bits);
+      const uint32_t slot = atomicAdd(&s_cnt[p], 1u);
+      if (slot < (uint32_t)S) {
+        st_keys[(size_t)p * S + slot] = cur_key;
+#pragma unroll
+        for (int v = 0; v < MOVE_MAX_INPUTS; ++v)
+          if ((uint32_t)v < n_in) st_vals[((size_t)v * P + p) * S + slot] = cur_val[v];
+      } else {
+        const uint32_t pos = atomicAdd(&s_cur[p], 1u);  // stage full: straight to memory
+        out_keys[pos] = cur_key;
+#pragma unroll
+        for (int v = 0; v < MOVE_MAX_INPUTS; ++v)
+          if ((uint32_t)v < n_in) out_vals[(uint64_t)v * sp.capacity + pos] = cur_val[v];
+      }
+    }
+    __syncthreads();
+    flush(flush_at);
+    __syncthreads();
+  }
+  flush(1);
+}
+
+// One ticket = one partition: all its rows folded into a fresh LDS table, the table flushed into
+// the global one.  A partition holds (groups / partitions) distinct keys, chosen by the host to fit.
+__global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(const PartArgs A) {
+  extern __shared__ unsigned long long lds_raw[];
+  __shared__ unsigned long long s_ticket;
+  const uint32_t lane = lane_id();
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t n_waves = blockDim.x >> 6;
+  LdsTable L;
+  agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, A.n_accs);
+  SpillState none;
+  none.keys = nullptr;
+  none.vals = nullptr;
+  none.capacity = 0;
+  none.base = 0;
+  none.cursor = 0;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd(A.ticket, 1ull);
+    agg_lds_clear(L, A.accs, A.n_accs);  // ends with a barrier
+    const int64_t p = (int64_t)s_ticket;
+    if (p >= A.n_parts) break;
+    const int64_t start = A.offsets[p * A.stride];
+    const int64_t end = p + 1 < A.n_parts ? (int64_t)A.offsets[(p + 1) * A.stride] : A.total;
+    for (int64_t r0 = start + (int64_t)wave * VM_WAVE_ROWS; r0 < end; r0 += (int64_t)n_waves * VM_WAVE_ROWS) {
+      AggRows G;
+      uint32_t active = 0;
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) {
+        const int64_t r = r0 + j * 64 + lane;
+        G.key[j] = 0;
+        G.slot[j] = SLOT_NONE;
+        if (r < end) {
+          G.key[j] = A.keys[r];
+          active |= 1u << j;
+        }
+      }
+      G.rem = 0;
+      G.lead_mb = 0;
+      G.lead_slot = SLOT_NONE;
+      agg_lookup<false>(L, A.table, active, lane, G, none);
+#pragma unroll 1
+      for (int v = 0; v < A.n_inputs; ++v) {
+        Slot in;
+        in.valid = 0xFu;
+#pragma unroll
+        for (int j = 0; j < VM_R; ++j) {
+          const int64_t r = r0 + j * 64 + lane;
+          in.v[j] = r < end ? A.vals[(uint64_t)v * A.capacity + r] : 0ull;
+        }
+#pragma unroll 1
+        for (int a = 0; a < A.n_accs; ++a)
+          if (A.acc_col[a] == v) agg_fold(L, A.table, a, A.accs[a].op, A.accs[a].in_type, false, in, G, lane);
+      }
+    }
+    agg_flush(L, A.table, A.accs, A.n_accs);  // starts with a barrier
+  }
 }
 
 // ------------------------------------------------------ table init/finalize
@@ -230,9 +442,15 @@ __global__ __launch_bounds__(256) void qe_finalize_kernel(const FinalizeArgs A) 
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= T.cap;
        i += (uint64_t)gridDim.x * blockDim.x) {
     unsigned long long k = T.keys[i];
-    if (k == AGG_EMPTY_KEY) continue;
+    // output position: one atomic per wave for all its occupied slots, not one per slot
+    const bool occupied = k != AGG_EMPTY_KEY;
+    const uint64_t occ = __ballot(occupied);
+    unsigned long long wave_base = 0;
+    if (occ != 0 && lane_id() == (uint32_t)__builtin_ctzll(occ)) wave_base = atomicAdd(A.out_count, (unsigned long long)__popcll(occ));
+    wave_base = readlane64(wave_base, occ != 0 ? __builtin_ctzll(occ) : 0);
+    if (!occupied) continue;
     if (i == T.cap) k = AGG_EMPTY_KEY;  // reserved slot holds the marker-valued key
-    unsigned long long pos = atomicAdd(A.out_count, 1ull);
+    unsigned long long pos = wave_base + mbcnt64(occ);
     for (int o = 0; o < A.n_outs; ++o) {
       const FinOut &f = A.outs[o];
       uint64_t val = 0;
@@ -516,8 +734,7 @@ uint32_t aggregate_lds_slots(int n_accs, const DeviceInfo &dev, int64_t group_hi
   return slots;
 }
 
-hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name) {
-  if (args.n_rows <= 0) return hipSuccess;
+int aggregate_grid(const AggArgs &args, const DeviceInfo &dev) {
   size_t lds = agg_lds_bytes(args.n_accs, args.lds_cap);
   // Resident workgroups per compute unit: enough waves to keep about 96 KiB of column loads in
   // flight per compute unit (a wave has 2 KiB per cached column outstanding), within what the LDS
@@ -534,6 +751,13 @@ hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStrea
   int grid = grid_for(args.n_rows, VM_BLOCK_ROWS, dev.cus * per_cu);
   static int forced_grid = tuned("QE_AGGREGATE_GRID", 0);
   if (forced_grid > 0) grid = grid_for(args.n_rows, VM_BLOCK_ROWS, forced_grid);
+  return grid;
+}
+
+hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name) {
+  if (args.n_rows <= 0) return hipSuccess;
+  size_t lds = agg_lds_bytes(args.n_accs, args.lds_cap);
+  int grid = aggregate_grid(args, dev);
   hipError_t err;
   if (dev.specialised && static_launch_aggregate(args, grid, lds, stream, &err, kernel_name)) return err;
   if (jit_wanted(dev, args.n_rows) &&
@@ -543,6 +767,57 @@ hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStrea
     hipLaunchKernelGGL(qe_aggregate_kernel<true>, dim3(grid), dim3(VM_BLOCK_THREADS), lds, stream, args);
   else
     hipLaunchKernelGGL(qe_aggregate_kernel<false>, dim3(grid), dim3(VM_BLOCK_THREADS), lds, stream, args);
+  return hipGetLastError();
+}
+
+size_t spill_cells(int bits, int blocks) { return ((size_t)1 << bits) * blocks; }
+
+hipError_t launch_spill_partition(const AggSpill &sp, int n_segments, int bits, int blocks, bool move, int32_t *cells,
+                                  unsigned long long *out_keys, unsigned long long *out_vals, unsigned long long *total,
+                                  hipStream_t stream) {
+  if (bits > PART_MAX_BITS) return hipErrorInvalidValue;
+  if (move) {
+    // stage depth from what 120 KiB of LDS hold; shallow stages are not worth their barriers
+    const size_t row_bytes = 8 * (1 + (size_t)sp.n_inputs);
+    int S = (int)((size_t)120 * 1024 / (((size_t)1 << bits) * row_bytes));
+    if (S > 16) S = 16;
+    if (S >= 4) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)qe_spill_move_staged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(qe_spill_move_staged_kernel, dim3(blocks), dim3(PART_THREADS), ((size_t)1 << bits) * S * row_bytes, stream, sp,
+                         n_segments, bits, S, cells, out_keys, out_vals);
+    } else {
+      hipLaunchKernelGGL(qe_spill_partition_kernel<true>, dim3(blocks), dim3(PART_THREADS), 0, stream, sp, n_segments, bits, cells, out_keys,
+                         out_vals, total);
+    }
+  } else {
+    hipLaunchKernelGGL(qe_spill_partition_kernel<false>, dim3(blocks), dim3(PART_THREADS), 0, stream, sp, n_segments, bits, cells, out_keys,
+                       out_vals, total);
+  }
+  return hipGetLastError();
+}
+
+// LDS slots of the partition-wise aggregate: as many as 144 KiB hold (one workgroup per compute unit).
+uint32_t partitioned_lds_slots(int n_accs) {
+  uint32_t slots = 8192;
+  while (slots > 64 && agg_lds_bytes(n_accs, slots) > (size_t)144 * 1024) slots >>= 1;
+  return slots;
+}
+
+hipError_t launch_aggregate_partitioned(const PartArgs &args, const DeviceInfo &dev, hipStream_t stream) {
+  size_t lds = agg_lds_bytes(args.n_accs, args.lds_cap);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)qe_aggregate_partitioned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  int grid = args.n_parts < dev.cus ? args.n_parts : dev.cus;
+  hipLaunchKernelGGL(qe_aggregate_partitioned_kernel, dim3(grid), dim3(PART_THREADS), lds, stream, args);
   return hipGetLastError();
 }
 

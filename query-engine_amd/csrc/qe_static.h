@@ -444,7 +444,7 @@ __device__ __forceinline__ void hot_fold(HotCache<Spec::n_accs> &C, const Slot &
 
 template <class Spec, int T>
 __device__ __forceinline__ void agg_tasks_static(const AggArgs &A, const LdsTable &L, RowCtx &c, const ColCache &K, AggRows &G,
-                                                 HotCache<Spec::n_accs> &C, uint32_t (&hm)[HOT_KEYS], uint32_t lane) {
+                                                 HotCache<Spec::n_accs> &C, uint32_t (&hm)[HOT_KEYS], SpillState &sp, uint32_t lane) {
   if constexpr (T < Spec::n_tasks) {
     constexpr uint32_t role = Spec::task_role[T], idx = Spec::task_idx[T];
     Slot S[VM_MAX_DEPTH];
@@ -466,13 +466,14 @@ __device__ __forceinline__ void agg_tasks_static(const AggArgs &A, const LdsTabl
 #pragma unroll
       for (int h = 0; h < HOT_KEYS; ++h) C.rows[h] += (uint32_t)__popc(hm[h]);
       // rows of other keys: LDS / global table (no dominant-key search: the hot keys took those)
-      agg_lookup<false>(L, A.table, rest, lane, G);
+      agg_lookup<false>(L, A.table, rest, lane, G, sp);
     } else {
       hot_fold<Spec, (int)idx>(C, S[0], hm);
+      if (G.spill_mb != 0 && A.spill_col[idx] != 0xffu) spill_values(sp, A.spill_col[idx], S[0], G);
       if (__ballot(G.rem != 0) != 0)
         agg_fold(L, A.table, idx, Spec::acc_op[idx], Spec::acc_type[idx], Spec::acc_track[idx] != 0, S[0], G, lane);
     }
-    agg_tasks_static<Spec, T + 1>(A, L, c, K, G, C, hm, lane);
+    agg_tasks_static<Spec, T + 1>(A, L, c, K, G, C, hm, sp, lane);
   }
 }
 
@@ -493,6 +494,7 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_aggregate_static(const
   C.key[0] = C.key[1] = 0;
   hot_reset<Spec, 0>(C, true);
   hot_reset<Spec, 1>(C, true);
+  SpillState sp = spill_begin(A.spill, wave);
 
   const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
   for (int64_t ws = (int64_t)blockIdx.x * VM_BLOCK_WAVES + wave; ws < nsteps;
@@ -510,9 +512,12 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_aggregate_static(const
     G.rem = 0;
     G.lead_mb = 0;
     G.lead_slot = SLOT_NONE;
+    G.spill_mb = 0;
+    G.spill_pos = 0;
     uint32_t hm[HOT_KEYS] = {0, 0};
-    agg_tasks_static<Spec, 0>(A, L, c, K, G, C, hm, lane);
+    agg_tasks_static<Spec, 0>(A, L, c, K, G, C, hm, sp, lane);
   }
+  spill_end(A.spill, sp, wave, lane);
   hot_flush<Spec, 0>(C, A.table, lane, (C.valid & 1u) != 0);
   hot_flush<Spec, 1>(C, A.table, lane, (C.valid & 2u) != 0);
   agg_flush(L, A.table, A.accs, Spec::n_accs);

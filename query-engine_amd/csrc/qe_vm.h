@@ -187,6 +187,20 @@ struct VmTask {
 };
 constexpr int VM_MAX_TASKS = 2 + VM_MAX_KEYS + VM_MAX_ACCS;
 
+// High-cardinality mode.  Rows whose key finds no room in the workgroup's LDS table are not sent
+// to the global table one atomic at a time (scattered global atomics run at a few per cent of the
+// memory rate); each wave appends them (packed key + the distinct accumulator inputs) to a
+// region of its own, and a second phase partitions that log by key hash and aggregates it
+// partition by partition in LDS.  keys == nullptr: off.
+struct AggSpill {
+  unsigned long long *keys;  // [capacity]
+  unsigned long long *vals;  // [n_inputs][capacity] raw input values
+  uint32_t *counts;          // [waves of the launch] rows each wave spilled
+  uint64_t capacity;
+  uint32_t rows_per_wave;    // size of one wave's region
+  uint32_t n_inputs;
+};
+
 struct AggArgs {
   VmProgram prog;
   VmKey keys[VM_MAX_KEYS];
@@ -200,6 +214,27 @@ struct AggArgs {
   int64_t n_rows;
   uint32_t lds_cap;    // LDS table slots (power of two)
   uint32_t lds_limit;  // stop claiming LDS slots past this many
+  AggSpill spill;
+  uint8_t spill_col[VM_MAX_ACCS];  // value column an accumulator's input is logged to; 0xff: not this one
+};
+
+// Second phase of the high-cardinality mode: the spilled rows, partitioned by key hash.
+struct PartArgs {
+  const unsigned long long *keys;
+  const unsigned long long *vals;  // [n_inputs][capacity]
+  uint64_t capacity;
+  const int32_t *offsets;          // offsets[p * stride] = first row of partition p
+  int32_t n_parts;
+  int32_t stride;
+  int64_t total;                   // rows in all partitions
+  VmAcc accs[VM_MAX_ACCS];
+  uint8_t acc_col[VM_MAX_ACCS];    // value column of each accumulator
+  int32_t n_accs;
+  int32_t n_inputs;
+  AggTable table;
+  uint32_t lds_cap;
+  uint32_t lds_limit;
+  unsigned long long *ticket;      // zeroed before the launch
 };
 
 // One output column of the finalize pass.

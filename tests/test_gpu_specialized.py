@@ -126,3 +126,33 @@ def test_nullable_input_uses_interpreter(qe, ctx):
         assert not any("_static<" in k for k in ctx.profile_read())
     finally:
         ctx.profile(False)
+
+
+@pytest.mark.parametrize("n,n_keys,zipf", [(300_000, 100_000, False), (400_000, 1_000_000, True), (70_000, 200, False)])
+def test_high_cardinality_mode(qe, ctx, n, n_keys, zipf):
+    """A large group-count hint switches the aggregate to log-and-partition for the rows that miss the
+    LDS tables.  Same results on the specialised and the general kernels, and the second phase ran."""
+    r = rng(n)
+    if zipf:
+        k = (r.zipf(1.1, n) % n_keys).astype(np.int64) * 2654435761 % (2 ** 40)
+    else:
+        k = r.integers(-n_keys // 2, n_keys // 2, n).astype(np.int64)
+    cols = [orc.Array(orc.INT64, k), orc.Array(orc.FLOAT64, r.uniform(-100, 100, n))]
+    hint = 1 << 17
+    sum_count = [("sum", C(1)), ("count", None)]
+    four = [("sum", C(1)), ("min", C(1)), ("max", C(1)), ("avg", C(1))]
+    both_paths(qe, ctx, lambda: run_agg(qe, ctx, [cols], [C(0)], sum_count, hint=hint, what=f"spill sum,count n={n}"), "qe_aggregate")
+    both_paths(qe, ctx, lambda: run_agg(qe, ctx, [cols], [C(0)], four, hint=hint, what=f"spill four n={n}"), "qe_aggregate")
+    ctx.profile(True)
+    try:
+        ctx.profile_read()
+        # computed key and inputs, filter, two batches, int64 sum next to float64 min
+        cols3 = cols + [orc.Array(orc.INT64, r.integers(-2 ** 40, 2 ** 40, n))]
+        parts = [cols3, [orc.Array(a.type, a.values[:1000]) for a in cols3]]
+        run_agg(qe, ctx, parts, [("add", C(0), ("i64", 1))], [("sum", C(2)), ("min", ("mul", C(1), ("f64", 2.0))), ("max", C(2)), ("count", None)],
+                pred=("gt", C(1), ("f64", -50.0)), hint=hint, what="spill computed")
+        names = set(ctx.profile_read())
+    finally:
+        ctx.profile(False)
+    if n_keys >= 100_000:
+        assert "qe_aggregate_partitioned_kernel" in names, names
