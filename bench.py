@@ -291,6 +291,37 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
     dt, prof, out = timed(ctx, torch, c3, 5, 2)
     entry("C3_groupby_lowcard_500M", r3, dt, prof, "qe_aggregate", BYTES_PER_ROW["c3"], len(b3), {"groups": out.num_rows})
 
+    # C3 with an Int32 key (the reference's native integer width): 12 B/row
+    k32 = k[:r3].to(torch.int32)
+    b3i = [qe.Batch.from_torch(ctx, [k32[s:min(r3, s + args.batch_rows)], c[s:min(r3, s + args.batch_rows)]])
+           for s in range(0, r3, args.batch_rows)]
+
+    def c3i():
+        return list(qe.AggregateExec([qe.ScanExec(ctx, b3i)], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None)],
+                                     group_capacity_hint=64).execute())[0]
+    dt, prof, out = timed(ctx, torch, c3i, 5, 2)
+    entry("C3_groupby_lowcard_int32key_500M", r3, dt, prof, "qe_aggregate", 12, len(b3i), {"groups": out.num_rows})
+    del k32, b3i
+
+    # C5's plan with 1 M uniformly distributed groups (high-cardinality mode: log, partition, aggregate in LDS)
+    r5 = min(n, 500_000_000)
+    uk = torch.empty(r5, dtype=torch.int64, device=dev)
+    ctx.generate(1, 99, 0, r5, 0, 1_000_000, uk.data_ptr())
+    ctx.synchronize()
+    b5 = [qe.Batch.from_torch(ctx, [uk[s:min(r5, s + args.batch_rows)], a[s:min(r5, s + args.batch_rows)],
+                                    b[s:min(r5, s + args.batch_rows)], c[s:min(r5, s + args.batch_rows)]])
+          for s in range(0, r5, args.batch_rows)]
+
+    def c5m():
+        sel = qe.SelectionExec([qe.ScanExec(ctx, b5)], qe.GtExpression(C(3), qe.LiteralFloatExpression(0.5)))
+        proj = qe.ProjectionExec([sel], [C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
+        return list(qe.AggregateExec([proj], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None)],
+                                     group_capacity_hint=1_100_000).execute())[0]
+    dt, prof, out = timed(ctx, torch, c5m, 3, 1)
+    entry("C5_plan_1M_groups_500M", r5, dt, prof, "qe_aggregate_static", BYTES_PER_ROW["c5"], len(b5),
+          {"groups": out.num_rows, "kernels_ms_per_step": {kk: vv["ms"] / 3 for kk, vv in prof.items()}})
+    del uk, b5, out
+
     # C4: 1 M distinct zipf(1.1) Int64 keys, SUM / MIN / MAX / AVG of one float64 column
     r4 = min(n, 500_000_000)
     zk = torch.empty(r4, dtype=torch.int64, device=dev)
@@ -304,15 +335,19 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
                                      [qe.SumExpression(C(1)), qe.MinExpression(C(1)), qe.MaxExpression(C(1)), qe.AvgExpression(C(1))],
                                      group_capacity_hint=1_100_000).execute())[0]
     dt, prof, out = timed(ctx, torch, c4, 2, 1)
-    entry("C4_groupby_zipf_1Mkeys_500M", r4, dt, prof, "qe_aggregate", BYTES_PER_ROW["c4"], len(b4), {"groups": out.num_rows})
+    entry("C4_groupby_zipf_1Mkeys_500M", r4, dt, prof, "qe_aggregate_static", BYTES_PER_ROW["c4"], len(b4),
+          {"groups": out.num_rows, "kernels_ms_per_step": {kk: vv["ms"] / 2 for kk, vv in prof.items()},
+           "note": "bound by LDS atomics and the partition pass, not by HBM: see kernels_ms_per_step"})
     return res
 
 
 def cpu_baseline(rows, seed):
     """The reference-shaped CPU path (oracle/qe_oracle.c, one materialising pass per expression node,
-    filter_chunk over every column, single-pass hash aggregate), one thread, on a bounded sample of the
-    same synthetic table.  Reported beside the GPU number; never part of `value`."""
+    filter_chunk over every column, single-pass hash aggregate) on a bounded sample of the same synthetic
+    table.  `value` is one thread (the reference is single threaded); `all_cores` shards the rows over the
+    host threads this box gives one GPU job.  Reported beside the GPU number; never part of `value`."""
     import ctypes as Ct
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as orc
     L = orc.lib()
     n = rows
@@ -326,28 +361,61 @@ def cpu_baseline(rows, seed):
     L.orc_generate(0, Ct.c_uint64(seed + 3), Ct.c_int64(0), Ct.c_int64(n), Ct.c_double(-1), Ct.c_double(1), p(b))
     L.orc_generate(0, Ct.c_uint64(seed + 4), Ct.c_int64(0), Ct.c_int64(n), Ct.c_double(0), Ct.c_double(1), p(c))
     half = np.array([0.5])
-    mask = np.zeros((n + 7) // 8 + 8, np.uint8)
-    fk, fa, fb, fc = np.empty(n, np.int64), np.empty(n, np.float64), np.empty(n, np.float64), np.empty(n, np.float64)
-    t1, v = np.empty(n, np.float64), np.empty(n, np.float64)
     g = 64
-    ok, orows, onn = np.zeros(g, np.uint64), np.zeros(g, np.int64), np.zeros(g, np.int64)
-    osum = np.zeros(g, np.float64)
+
+    def shard_buffers(lo, hi):
+        m0 = hi - lo
+        return dict(mask=np.zeros((m0 + 7) // 8 + 8, np.uint8), fk=np.empty(m0, np.int64), fa=np.empty(m0, np.float64),
+                    fb=np.empty(m0, np.float64), fc=np.empty(m0, np.float64), t1=np.empty(m0, np.float64), v=np.empty(m0, np.float64))
+
+    def shard_pass(lo, hi, w):
+        """All passes over rows [lo, hi) into the preallocated buffers `w`: returns the shard's (keys, row counts, sums)."""
+        m0 = hi - lo
+        ks, as_, bs, cs = k[lo:hi], a[lo:hi], b[lo:hi], c[lo:hi]
+        ok, orows, onn = np.zeros(g, np.uint64), np.zeros(g, np.int64), np.zeros(g, np.int64)
+        osum = np.zeros(g, np.float64)
+        L.orc_cmp_f64(3, p(cs), p(half), Ct.c_int64(m0), 1, p(w["mask"]))                                 # c > 0.5
+        m = 0
+        for src, dst in ((ks, w["fk"]), (as_, w["fa"]), (bs, w["fb"]), (cs, w["fc"])):                    # filter_chunk: every column
+            m = L.orc_filter_fixed(8, p(src), None, Ct.c_int64(m0), p(w["mask"]), None, p(dst), None)
+        L.orc_arith_f64(11, p(w["fb"]), p(w["fc"]), Ct.c_int64(m), 0, p(w["t1"]))                         # b * c
+        L.orc_arith_f64(9, p(w["fa"]), p(w["t1"]), Ct.c_int64(m), 0, p(w["v"]))                           # a + (b*c)
+        ng = L.orc_hash_aggregate(p(w["fk"].view(np.uint64)), None, None, Ct.c_int64(m), 3, p(w["v"]), None, Ct.c_int64(g), p(ok),
+                                  p(orows), p(onn), p(osum), None, None, None, None, None)
+        return ok, orows, osum, ng
+
+    whole = shard_buffers(0, n)
+    shard_pass(0, n, whole)  # touch every page once, untimed
     reps, t_total = 0, 0.0
     while t_total < 10.0 and reps < 8:
         t0 = time.perf_counter()
-        L.orc_cmp_f64(3, p(c), p(half), Ct.c_int64(n), 1, p(mask))                                       # c > 0.5
-        m = 0
-        for src, dst in ((k, fk), (a, fa), (b, fb), (c, fc)):                                            # filter_chunk: every column
-            m = L.orc_filter_fixed(8, p(src), None, Ct.c_int64(n), p(mask), None, p(dst), None)
-        L.orc_arith_f64(11, p(fb), p(fc), Ct.c_int64(m), 0, p(t1))                                       # b * c
-        L.orc_arith_f64(9, p(fa), p(t1), Ct.c_int64(m), 0, p(v))                                         # a + (b*c)
-        L.orc_hash_aggregate(p(fk.view(np.uint64)), None, None, Ct.c_int64(m), 3, p(v), None, Ct.c_int64(g), p(ok), p(orows),
-                             p(onn), p(osum), None, None, None, None, None)
+        shard_pass(0, n, whole)
         t_total += time.perf_counter() - t0
         reps += 1
-    return {"value": n * reps / t_total, "unit": "rows/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} x {n} rows of the same synthetic table (seed {seed}), reference-shaped passes "
-                      "(cmp_scalar, filter x4 columns, mul, add, hash aggregate) in oracle/qe_oracle.c, -O3 -march=native"}
+    out = {"value": n * reps / t_total, "unit": "rows/s", "cores": 1, "kind": "port",
+           "sample": f"{reps} x {n} rows of the same synthetic table (seed {seed}), reference-shaped passes "
+                     "(cmp_scalar, filter x4 columns, mul, add, hash aggregate) in oracle/qe_oracle.c, -O3 -march=native"}
+    threads = max(1, min(16, os.cpu_count() or 1))
+    del whole
+    bounds = [(i * n // threads, (i + 1) * n // threads) for i in range(threads)]
+    bufs = [shard_buffers(lo, hi) for lo, hi in bounds]
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(lambda i: shard_pass(*bounds[i], bufs[i]), range(threads)))  # untimed warm-up
+        reps2, t2 = 0, 0.0
+        while t2 < 5.0 and reps2 < 8:
+            t0 = time.perf_counter()
+            parts = list(pool.map(lambda i: shard_pass(*bounds[i], bufs[i]), range(threads)))
+            merged = {}
+            for ok, orows, osum, ng in parts:                                                             # merge of the shard tables
+                for i in range(int(ng)):
+                    e = merged.setdefault(int(ok[i]), [0, 0.0])
+                    e[0] += int(orows[i])
+                    e[1] += float(osum[i])
+            t2 += time.perf_counter() - t0
+            reps2 += 1
+    out["all_cores"] = {"value": n * reps2 / t2, "unit": "rows/s", "cores": threads,
+                        "sample": f"{reps2} x {n} rows, row ranges over {threads} threads (ctypes releases the GIL), shard tables merged"}
+    return out
 
 
 if __name__ == "__main__":
