@@ -620,8 +620,19 @@ class AggregateExec(PhysicalPlan):
     def _single_pass(self, chunks):
         all_keys, all_valid, key_types = [], [], None
         per_agg = [[] for _ in self.agg_exprs]
+        # A single Utf8 group column is dictionary-encoded (codes in first-seen order over all chunks)
+        # and aggregated on the codes; the output key column holds the strings again.  arrow2 hashes
+        # utf8 arrays, so the reference groups by strings (its test_max groups by `country`).
+        dictionary = {}
+        utf8_key = False
         for ch in chunks:
             gk, ai = self._inputs(ch)
+            if any(a.type == UTF8 for a in gk):
+                if len(gk) != 1:
+                    raise OracleError("PhysicalTypeNotSuported", "a Utf8 group key must be the only group expression")
+                utf8_key = True
+                codes = np.array([dictionary.setdefault(sv, len(dictionary)) for sv in gk[0].strings()], dtype=np.int64)
+                gk = [Array(INT64, codes, gk[0].validity)]
             k, kv, _ = pack_keys(gk, len(ch))
             key_types = [a.type for a in gk]
             all_keys.append(k)
@@ -636,6 +647,11 @@ class AggregateExec(PhysicalPlan):
         if len(base["keys"]) == 0:
             raise OracleError("EmptyHashmapForAggregate")
         cols = unpack_key(base["keys"], key_types)
+        if utf8_key:
+            words = [None] * len(dictionary)
+            for sv, code in dictionary.items():
+                words[code] = sv
+            cols[0] = Array.from_python([words[int(c)] for c in cols[0].values])
         for j, e in enumerate(self.agg_exprs):
             arrs = per_agg[j]
             if e.expr is None:

@@ -191,6 +191,20 @@ ExprPtr make_binary(int op, ExprPtr l, ExprPtr r) {
   return e;
 }
 
+ExprPtr make_hash_utf8(ExprPtr column) {
+  auto n = std::make_shared<Expr>();
+  n->kind = EK_HASH_UTF8;
+  n->l = std::move(column);
+  return n;
+}
+
+ExprPtr make_rowid(int64_t base) {
+  auto n = std::make_shared<Expr>();
+  n->kind = EK_ROWID;
+  n->ival = base;
+  return n;
+}
+
 static const char *op_symbol(int op) {
   switch (op) {
     case QE_OP_EQ: return "==";
@@ -229,6 +243,8 @@ std::string expr_to_string(const ExprPtr &e) {
       if (e->to_f64) { o << "float64(" << expr_to_string(e->l) << ")"; break; }
       o << expr_to_string(e->l) << " " << op_symbol(e->op) << " " << expr_to_string(e->r);
       break;
+    case EK_HASH_UTF8: o << "hash(" << expr_to_string(e->l) << ")"; break;
+    case EK_ROWID: o << "rowid(" << e->ival << ")"; break;
   }
   return o.str();
 }
@@ -237,6 +253,8 @@ bool expr_is_scalar(const ExprPtr &e) {
   switch (e->kind) {
     case EK_COLUMN: return false;
     case EK_LITERAL: return true;
+    case EK_HASH_UTF8:
+    case EK_ROWID: return false;
     default: return expr_is_scalar(e->l) && (e->to_f64 || expr_is_scalar(e->r));
   }
 }
@@ -253,6 +271,11 @@ int expr_type(const ExprPtr &e, const Schema &schema) {
       return schema[e->index].type;
     case EK_LITERAL:
       return e->type;
+    case EK_HASH_UTF8:
+      if (expr_type(e->l, schema) != QE_TYPE_UTF8) fail(QE_ERR_INTERNAL, "hash of a non-utf8 column");
+      return QE_TYPE_INT64;
+    case EK_ROWID:
+      return QE_TYPE_INT64;
     default: {
       int lt = expr_type(e->l, schema);
       if (e->to_f64) {
@@ -289,6 +312,8 @@ bool expr_nullable(const ExprPtr &e, const Schema &schema) {
   switch (e->kind) {
     case EK_COLUMN: return e->index >= 0 && e->index < (int)schema.size() && schema[e->index].nullable;
     case EK_LITERAL: return !e->valid;
+    case EK_HASH_UTF8: return expr_nullable(e->l, schema);
+    case EK_ROWID: return false;
     default: {
       if (e->to_f64) return expr_nullable(e->l, schema);
       bool n = expr_nullable(e->l, schema) || expr_nullable(e->r, schema);
@@ -304,6 +329,7 @@ ExprPtr expr_substitute(const ExprPtr &e, const std::vector<ExprPtr> &outputs) {
       if (e->index < 0 || e->index >= (int)outputs.size()) fail(QE_ERR_PRIMITIVE_TYPE_NOT_SUPPORTED, "Primitive type `Int32` is not supported.");
       return outputs[e->index];
     case EK_LITERAL:
+    case EK_ROWID:
       return e;
     default: {
       auto n = std::make_shared<Expr>(*e);
@@ -418,6 +444,7 @@ static int count_nodes(const ExprPtr &e) {
 }
 static void collect_cols(const ExprPtr &e, std::map<int, int> &seen) {
   if (e->kind == EK_COLUMN) seen[e->index] = 1;
+  if (e->kind == EK_HASH_UTF8) collect_cols(e->l, seen);
   if (e->kind == EK_BINARY) {
     collect_cols(e->l, seen);
     if (e->r) collect_cols(e->r, seen);
@@ -538,6 +565,20 @@ void Compiler::emit(const ExprPtr &e, int depth) {
       if (e->type == QE_TYPE_FLOAT64) std::memcpy(&bits, &e->fval, 8);
       else bits = (uint64_t)e->ival;
       push_insn(OP_PUSH_LIT, depth, lit_slot(bits));
+      return;
+    }
+    case EK_HASH_UTF8: {
+      if (e->l->kind != EK_COLUMN) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "A Utf8 group key must be a column.");
+      push_insn(OP_HASH_UTF8, depth, (uint32_t)col_slot(e->l->index));
+      return;
+    }
+    case EK_ROWID: {
+      push_insn(OP_PUSH_ROWID, depth, 0);
+      if (e->ival != 0) {
+        if (depth + 1 >= VM_MAX_DEPTH) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression is nested too deeply.");
+        push_insn(OP_PUSH_LIT, depth + 1, lit_slot((uint64_t)e->ival));
+        push_insn(OP_ADD_I64, depth + 2, 0);
+      }
       return;
     }
     default: break;

@@ -94,7 +94,14 @@ int type_width(int type);         // bytes per value of a fixed-width type (0 ot
 const char *type_name(int type);
 
 // ------------------------------------------------------------- expressions
-enum ExprKind { EK_COLUMN = 0, EK_LITERAL = 1, EK_BINARY = 2 };
+enum ExprKind {
+  EK_COLUMN = 0,
+  EK_LITERAL = 1,
+  EK_BINARY = 2,
+  // internal, made by the aggregate lowering only:
+  EK_HASH_UTF8 = 3,  // 64-bit hash of the utf8 column `l` (a string group key is aggregated by its hash)
+  EK_ROWID = 4       // global row number: `ival` (rows of the earlier batches) + row in the batch
+};
 
 struct Expr;
 using ExprPtr = std::shared_ptr<const Expr>;
@@ -124,6 +131,8 @@ ExprPtr make_lit_f64(double v);
 ExprPtr make_lit_bool(bool v);
 ExprPtr make_lit_utf8(const std::string &s);
 ExprPtr make_binary(int op, ExprPtr l, ExprPtr r);
+ExprPtr make_hash_utf8(ExprPtr column);
+ExprPtr make_rowid(int64_t base);
 std::string expr_to_string(const ExprPtr &e);
 bool expr_is_scalar(const ExprPtr &e);
 

@@ -131,6 +131,15 @@ __device__ __forceinline__ bool utf8_equal(const uint8_t *a, const uint8_t *b, i
   return true;
 }
 
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return x;
+}
+
 // ------------------------------------------------------- per-step column cache
 // Raw bits of up to VM_NCACHE columns for the 4 rows of the lane.  Filled by cache_load with
 // every load in flight at once; only ever indexed with compile-time constants.
@@ -351,7 +360,7 @@ __device__ __forceinline__ void vm_slow(uint32_t op, uint32_t d, uint32_t arg, c
   c.n = c0.n;
   c.active = c0.active;
   c.lane = opaque(c0.lane);
-  const bool is_push = (op <= OP_PUSH_ROWID) || (op >= OP_UTF8_EQ_LIT && op <= OP_UTF8_NE_COL);
+  const bool is_push = (op <= OP_PUSH_ROWID) || (op >= OP_UTF8_EQ_LIT && op <= OP_HASH_UTF8);
   const bool is_unary = op == OP_I64_TO_F64;
   Slot a, b;
   uint32_t dst;
@@ -444,6 +453,25 @@ __device__ __forceinline__ void vm_slow(uint32_t op, uint32_t d, uint32_t arg, c
       uint32_t va = ca.validity ? load_bits4(ca.validity, c) : 0xFu;
       uint32_t vb = (!vs_lit && cb.validity) ? load_bits4(cb.validity, c) : 0xFu;
       a.valid = va & vb;
+      break;
+    }
+    case OP_HASH_UTF8: {
+      // FNV-1a over the bytes, finished with a 64-bit mixer; rolled over the four rows
+      const VmCol &ca = P.cols[arg];
+      uint32_t act = c.active;
+#pragma unroll 1
+      for (int it = 0; it < VM_R; ++it) {
+        uint64_t h = 0xcbf29ce484222325ull;
+        if (act & 1u) {
+          int64_t r = c.row0 + (it >> 1) * 128 + 2 * (int64_t)c.lane + (it & 1);
+          const uint8_t *p = (const uint8_t *)ca.values;
+          for (int32_t i = ca.offsets[r], e = ca.offsets[r + 1]; i < e; ++i) h = (h ^ p[i]) * 0x100000001b3ull;
+        }
+        a.v[0] = mix64(h);
+        QE_ROT4(a.v);
+        act = rot4(act);
+      }
+      a.valid = ca.validity ? load_bits4(ca.validity, c) : 0xFu;
       break;
     }
     case OP_SWAP: {
@@ -701,15 +729,6 @@ __device__ __forceinline__ void store_compact(const VmOut &o, unsigned long long
 }
 
 // --------------------------------------------------------- aggregate kernel
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {
-  x ^= x >> 33;
-  x *= 0xff51afd7ed558ccdull;
-  x ^= x >> 33;
-  x *= 0xc4ceb9fe1a85ec53ull;
-  x ^= x >> 33;
-  return x;
-}
-
 // Order-preserving unsigned image: min/max of the images = image of the min/max.
 // float64: -0.0 < +0.0 and NaN never reaches here (NaN inputs are skipped).
 __device__ __forceinline__ uint64_t ord_image(uint64_t bits, uint32_t type) {

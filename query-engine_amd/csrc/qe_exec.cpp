@@ -149,6 +149,44 @@ static Column utf8_gather_column(Context *ctx, const Column &src, const int64_t 
   return c;
 }
 
+// A utf8 column of one scanned batch and the global row number of its first row.
+struct Utf8KeySource {
+  Column col;
+  int64_t first_row;
+};
+
+// Strings of the rows `ids` (global row numbers over the batches of `sources`), as a new utf8 column.
+static Column utf8_gather_rows(Context *ctx, const std::vector<Utf8KeySource> &sources, const int64_t *ids, int64_t m) {
+  std::vector<Utf8Source> table;
+  for (auto &s : sources) table.push_back(Utf8Source{s.col.offsets_ptr(), (const uint8_t *)s.col.values_ptr(), s.first_row});
+  BufferPtr dev_table = device_buffer(ctx, table.size() * sizeof(Utf8Source) + 16);
+  QE_HIP(hipMemcpyAsync(dev_table->ptr, table.data(), table.size() * sizeof(Utf8Source), hipMemcpyHostToDevice, ctx->stream));
+  Column c;
+  c.type = QE_TYPE_UTF8;
+  c.space = QE_MEM_DEVICE;
+  c.length = m;
+  c.offsets = device_buffer(ctx, (size_t)(m + 1) * 4 + 16);
+  int32_t *offs = (int32_t *)c.offsets->ptr;
+  QE_HIP(hipMemsetAsync(offs + m, 0, 4, ctx->stream));
+  ctx->prof_begin("qe_utf8_gather_rows_kernel");
+  QE_HIP(launch_utf8_gather_rows((const Utf8Source *)dev_table->ptr, (int)table.size(), ids, m, offs, nullptr, nullptr, ctx->stream));
+  ctx->prof_end();
+  BufferPtr scan_tmp = device_buffer(ctx, scan_scratch_elems(m + 1) * 4 + 64);
+  QE_HIP(launch_exclusive_scan_i32(offs, m + 1, (int32_t *)scan_tmp->ptr, ctx->stream));
+  ensure_counters(ctx);
+  QE_HIP(hipMemcpyAsync(ctx->host_counters + 8, offs + m, 4, hipMemcpyDeviceToHost, ctx->stream));
+  ctx->sync();  // also: `table` (host) has been read
+  int32_t total = *(int32_t *)(ctx->host_counters + 8);
+  c.values_bytes = total;
+  c.values = device_buffer(ctx, (size_t)total + 16);
+  ctx->prof_begin("qe_utf8_gather_rows_kernel");
+  QE_HIP(launch_utf8_gather_rows((const Utf8Source *)dev_table->ptr, (int)table.size(), ids, m, nullptr, offs, (uint8_t *)c.values->ptr,
+                                 ctx->stream));
+  ctx->prof_end();
+  ctx->sync();  // `dev_table` goes back to the pool on return
+  return c;
+}
+
 // ---------------------------------------------------------------- lowering
 // Expression trees -> kernel arguments, apart from output buffers: those come from `sink`, so
 // that the same code serves execution (buffers from the pool) and qe_lowering_describe (none).
@@ -351,15 +389,18 @@ struct AggSpec {
   std::vector<ExprPtr> key_exprs;
   std::vector<AccDesc> accs;
   std::vector<FinOut> outs;  // pointers filled at finalize time
+  int utf8_key_out = -1;     // output column that holds representative row numbers of a utf8 key
+  int utf8_key_col = -1;     // ... and the source column the strings come from
 };
 
 static int add_acc(AggSpec &spec, uint8_t op, int in_type, bool track_nn, const ExprPtr &input) {
   // aggregates over the same input share one accumulator (AVG(x) next to SUM(x) / COUNT(x))
-  std::string key = input ? expr_to_string(input) : std::string();
+  // the row-number input differs between batches only in its base: one accumulator all the same
+  std::string key = input ? (input->kind == EK_ROWID ? std::string("rowid") : expr_to_string(input)) : std::string();
   for (size_t i = 0; i < spec.accs.size(); ++i) {
     AccDesc &d = spec.accs[i];
     if (d.acc.op == op && d.acc.in_type == (uint8_t)in_type && (d.input != nullptr) == (input != nullptr) &&
-        (!input || expr_to_string(d.input) == key)) {
+        (!input || (d.input->kind == EK_ROWID ? std::string("rowid") : expr_to_string(d.input)) == key)) {
       if (track_nn) d.acc.track_nn = 1;
       return (int)i;
     }
@@ -398,15 +439,35 @@ static ExprPtr make_to_f64(const ExprPtr &e) {
 static bool numeric(int t) { return t == QE_TYPE_INT32 || t == QE_TYPE_INT64 || t == QE_TYPE_FLOAT64; }
 
 static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::vector<ExprPtr> &groups,
-                              const std::vector<AggExpr> &aggs, const std::vector<ExprPtr> &aggs_second, int mode) {
+                              const std::vector<AggExpr> &aggs, const std::vector<ExprPtr> &aggs_second, int mode,
+                              int64_t row_base = 0) {
   AggSpec spec;
   int shift = 0;
   if ((int)groups.size() > VM_MAX_KEYS) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many group expressions.");
   for (size_t g = 0; g < groups.size(); ++g) {
     ExprPtr e = expr_normalize(groups[g], flags);
     int t = expr_type(e, schema);
+    if (t == QE_TYPE_UTF8) {
+      // A string key is aggregated by a 64-bit hash of its bytes (the reference identifies groups by
+      // hash alone, physical_plan/mod.rs:317-358); the smallest row number of the group is kept as a
+      // hidden accumulator and the output key column is gathered from those rows.
+      if (groups.size() != 1 || e->kind != EK_COLUMN)
+        fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "A Utf8 group key must be a plain column and the only group expression.");
+      VmKey k{};
+      k.type = (uint8_t)QE_TYPE_UTF8;
+      k.shift = 0;
+      k.bits = 64;
+      spec.keys.push_back(k);
+      spec.key_exprs.push_back(make_hash_utf8(e));
+      int a = add_acc(spec, ACC_MIN, QE_TYPE_INT64, false, make_rowid(row_base));
+      spec.utf8_key_out = (int)spec.outs.size();
+      spec.utf8_key_col = e->index;
+      spec.outs.push_back(fin(FIN_ACC_ORD, QE_TYPE_INT64, a, a, CNT_ROWS, NULL_NEVER));
+      shift = 64;
+      continue;
+    }
     int bits = t == QE_TYPE_INT32 ? 32 : t == QE_TYPE_INT64 ? 64 : t == QE_TYPE_BOOLEAN ? 1 : 0;
-    // arrow2 cannot hash floats (the reference unwrap()s: physical_plan/mod.rs:317); utf8 keys are not lowered yet
+    // arrow2 cannot hash floats (the reference unwrap()s: physical_plan/mod.rs:317)
     if (bits == 0) fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, std::string("Physical type `") + type_name(t) + "` is not supported as a group key.");
     if (shift + bits > 64) fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "Group key wider than 64 bits is not supported.");
     VmKey k{};
@@ -662,6 +723,8 @@ struct AggIter : Iter {
       AggTable table{};
       BufferPtr table_buf;
       std::vector<int> key_types, acc_types;
+      std::vector<Utf8KeySource> key_sources;
+      int64_t row_base = 0;
       Batch in;
       while (s.src->next(in)) {
         int ncols = (int)in.cols.size();
@@ -681,7 +744,9 @@ struct AggIter : Iter {
           a2_second.push_back(second);
         }
         Schema schema = schema_of(in);
-        AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode);
+        AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode, row_base);
+        if (bspec.utf8_key_col >= 0) key_sources.push_back(Utf8KeySource{in.cols[bspec.utf8_key_col], row_base});
+        row_base += in.rows;
         if (!have_table) {
           spec = bspec;
           int na = (int)spec.accs.size();
@@ -759,6 +824,10 @@ struct AggIter : Iter {
       ctx->prof_begin("qe_finalize_kernel");
       QE_HIP(launch_finalize(fa, ctx->stream));
       ctx->prof_end();
+      if (spec.utf8_key_out >= 0) {
+        Column &ids = result.cols[spec.utf8_key_out];
+        result.cols[spec.utf8_key_out] = utf8_gather_rows(ctx, key_sources, (const int64_t *)ids.values->ptr, (int64_t)n_groups);
+      }
       ctx->sync();
       done = true;
       return;

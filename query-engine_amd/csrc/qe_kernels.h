@@ -55,6 +55,15 @@ hipError_t launch_exclusive_scan_i32(int32_t *data, int64_t n, int32_t *block_su
 size_t scan_scratch_elems(int64_t n);
 hipError_t launch_utf8_gather_bytes(const int32_t *src_offsets, const uint8_t *src_bytes, const int64_t *idx, int64_t m,
                                     const int32_t *dst_offsets, uint8_t *dst_bytes, hipStream_t stream);
+// Gather of strings by global row number over several source columns (group-by output keys).
+// Pass out_lengths to get the lengths (first pass), dst_offsets + dst_bytes to copy the bytes.
+struct Utf8Source {
+  const int32_t *offsets;
+  const uint8_t *bytes;
+  int64_t first_row;  // global row number of the source's first row; sources are in ascending order
+};
+hipError_t launch_utf8_gather_rows(const Utf8Source *sources, int n_sources, const int64_t *ids, int64_t m, int32_t *out_lengths,
+                                   const int32_t *dst_offsets, uint8_t *dst_bytes, hipStream_t stream);
 // Broadcast one utf8 literal to `n` rows (scalar_to_array for Utf8, columnar_value.rs:40-50).
 hipError_t launch_utf8_broadcast(const uint8_t *lit, int32_t len, int64_t n, int32_t *out_offsets, uint8_t *out_bytes,
                                  hipStream_t stream);

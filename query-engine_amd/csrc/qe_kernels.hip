@@ -563,6 +563,23 @@ __global__ void qe_utf8_gather_bytes_kernel(const int32_t *src_offsets, const ui
   }
 }
 
+__global__ void qe_utf8_gather_rows_kernel(const Utf8Source *sources, int n_sources, const int64_t *ids, int64_t m, int32_t *out_lengths,
+                                           const int32_t *dst_offsets, uint8_t *dst_bytes) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t id = ids[i];
+    int s = n_sources - 1;
+    while (s > 0 && sources[s].first_row > id) --s;
+    const int64_t r = id - sources[s].first_row;
+    const int32_t s0 = sources[s].offsets[r], len = sources[s].offsets[r + 1] - s0;
+    if (out_lengths) {
+      out_lengths[i] = len;
+    } else {
+      const int32_t d0 = dst_offsets[i];
+      for (int32_t b = 0; b < len; ++b) dst_bytes[d0 + b] = sources[s].bytes[s0 + b];
+    }
+  }
+}
+
 __global__ void qe_utf8_broadcast_kernel(const uint8_t *lit, int32_t len, int64_t n, int32_t *out_offsets,
                                          uint8_t *out_bytes) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -874,6 +891,14 @@ hipError_t launch_utf8_gather_bytes(const int32_t *src_offsets, const uint8_t *s
   if (m <= 0) return hipSuccess;
   hipLaunchKernelGGL(qe_utf8_gather_bytes_kernel, dim3(grid_for(m, 256, 4096)), dim3(256), 0, stream, src_offsets,
                      src_bytes, idx, m, dst_offsets, dst_bytes);
+  return hipGetLastError();
+}
+
+hipError_t launch_utf8_gather_rows(const Utf8Source *sources, int n_sources, const int64_t *ids, int64_t m, int32_t *out_lengths,
+                                   const int32_t *dst_offsets, uint8_t *dst_bytes, hipStream_t stream) {
+  if (m <= 0) return hipSuccess;
+  hipLaunchKernelGGL(qe_utf8_gather_rows_kernel, dim3(grid_for(m, 256, 4096)), dim3(256), 0, stream, sources, n_sources, ids, m, out_lengths,
+                     dst_offsets, dst_bytes);
   return hipGetLastError();
 }
 

@@ -51,14 +51,15 @@ enum VmOp : uint32_t {
   // utf8 comparisons push their boolean result directly.
   OP_UTF8_EQ_LIT, OP_UTF8_NE_LIT,  // arg = col | lit<<8 (lits[lit] = device ptr, lits[lit+1] = length)
   OP_UTF8_EQ_COL, OP_UTF8_NE_COL,  // arg = colA | colB<<8
+  OP_HASH_UTF8,                    // arg = column: 64-bit hash of the string (group key), null string -> null
   OP_I64_TO_F64,                   // top slot: int64 -> float64 (AVG over integers)
   // pushes out of the per-step column cache (arg = cache slot)
   OP_PUSH_CACHED64, OP_PUSH_CACHED32, OP_PUSH_CACHEDBOOL,
   OP_COUNT_
 };
 
-// Instructions the shape-specialised kernels implement: everything except the utf8 comparisons.
-constexpr bool vm_op_specialisable(uint32_t op) { return op < OP_COUNT_ && !(op >= OP_UTF8_EQ_LIT && op <= OP_UTF8_NE_COL); }
+// Instructions the shape-specialised kernels implement: everything except the utf8 comparisons and hash.
+constexpr bool vm_op_specialisable(uint32_t op) { return op < OP_COUNT_ && !(op >= OP_UTF8_EQ_LIT && op <= OP_HASH_UTF8); }
 
 inline uint32_t vm_insn(uint32_t op, uint32_t depth, uint32_t arg) { return op | (depth << 8) | (arg << 12); }
 

@@ -369,3 +369,62 @@ def test_partial_final_aggregate(qe, ctx):
             assert (np.abs(av[vm] - bv[vm]) <= tol[i][pw][vm]).all(), i
         else:
             assert np.array_equal(av[vm], bv[vm]), i
+
+
+def _by_key(cols_or_arrays, is_oracle):
+    """{key string: tuple of the other columns' values (None for null)} of an aggregate output."""
+    if is_oracle:
+        lists = [a.to_pylist() for a in cols_or_arrays]
+    else:
+        lists = []
+        for c in cols_or_arrays:
+            vals = list(c.values)
+            if c.validity is not None:
+                vals = [v if ok else None for v, ok in zip(vals, c.validity)]
+            lists.append([v.decode() if isinstance(v, bytes) else (v.item() if hasattr(v, "item") else v) for v in vals])
+    return {lists[0][i]: tuple(l[i] for l in lists[1:]) for i in range(len(lists[0]))}
+
+
+def test_utf8_group_key(qe, ctx):
+    """GROUP BY a string column: the shape of the reference's own aggregate test
+    (tests/mod.rs:190-207: aggregate([country], [max(salary)])), here with every aggregate, against the
+    oracle and against the per-country statistics derived from the reference's fixture with pyarrow."""
+    arrays, exp = load_userdata()
+    ci, si = COL["country"], COL["salary"]
+    aggs = [("max", C(si)), ("min", C(si)), ("sum", C(si)), ("count", C(si)), ("count", None), ("avg", C(si))]
+
+    def build(m, scan):
+        return m.AggregateExec([scan], [mk(m, C(ci))], [mk(m, a) for a in aggs])
+    third = [slice(0, 333), slice(333, 334), slice(334, 1000)]
+
+    def cut(a, s):
+        if a.type == orc.UTF8:
+            return orc.Array.from_python([x if (a.validity is None or a.validity[i]) else None
+                                          for i, x in zip(range(len(a))[s], a.strings()[s])])
+        return orc.Array(a.type, a.values[s], None if a.validity is None else a.validity[s])
+    for parts in ([arrays], [[cut(a, s) for a in arrays] for s in third]):
+        want = _by_key(list(build(orc, orc.ScanExec([orc.Chunk(p) for p in parts])).execute())[0].arrays, True)
+        got = _by_key(list(build(qe, qe.ScanExec(ctx, [gpu_batch(qe, ctx, p) for p in parts])).execute())[0].columns(), False)
+        assert set(got) == set(want) and len(got) == 120
+        for name, w in want.items():
+            g = got[name]
+            assert g[0] == w[0] and g[1] == w[1] and g[3] == w[3] and g[4] == w[4], name     # max, min, counts: exact
+            for a, b in ((g[2], w[2]), (g[5], w[5])):                                             # sum, avg: 1e-12 relative
+                assert (a is None) == (b is None) and (a is None or abs(a - b) <= 1e-12 * max(1.0, abs(b) * 100)), name
+            st = exp["country_stats"][name]
+            assert g[0] == st["max"] and g[1] == st["min"] and g[3] == st["nn"] and g[4] == st["rows"], name
+    # a filter in front, and null keys (dropped like any null key)
+    keyed = list(arrays)
+    kv = rng(5).random(1000) > 0.1
+    keyed[ci] = orc.Array.from_python([x if ok else None for x, ok in zip(arrays[ci].strings(), kv)])
+    pred = ("eq", C(COL["gender"]), ("str", "Female"))
+
+    def build2(m, scan):
+        return m.AggregateExec([m.SelectionExec([scan], mk(m, pred))], [mk(m, C(ci))], [mk(m, ("max", C(si))), mk(m, ("count", None))])
+    want = _by_key(list(build2(orc, orc.ScanExec([orc.Chunk(keyed)])).execute())[0].arrays, True)
+    got = _by_key(list(build2(qe, qe.ScanExec(ctx, [gpu_batch(qe, ctx, keyed)])).execute())[0].columns(), False)
+    assert got == want
+    with pytest.raises(qe.QeError) as e:
+        list(qe.AggregateExec([qe.ScanExec(ctx, [gpu_batch(qe, ctx, arrays)])], [qe.ColumnExpression(ci), qe.ColumnExpression(COL["id"])],
+                              [qe.MaxExpression(qe.ColumnExpression(si))]).execute())
+    assert e.value.name == "PhysicalTypeNotSuported"
