@@ -256,6 +256,56 @@ qe_status qe_generate_column(qe_context *ctx, int32_t kind, uint64_t seed, int64
 qe_status qe_context_profile(qe_context *ctx, int32_t enable);
 qe_status qe_context_profile_read(qe_context *ctx, char *buf, int64_t buf_len, int64_t *needed);
 
+/* ---------------------------------------------------------------------------
+ * The callers of the physical path: logical expressions, the DataFrame builder
+ * and the planner that lowers a logical plan onto the operators above.
+ * ------------------------------------------------------------------------- */
+typedef struct qe_logical_expr qe_logical_expr;
+typedef struct qe_dataframe qe_dataframe;
+
+/* prelude.rs:7-25: col, lit_string, lit_int (i32), lit_float, lit_bool.
+ * qe_lit_int64 is an extension. */
+qe_status qe_col(const char *name, qe_logical_expr **out);
+qe_status qe_lit_string(const char *value, qe_logical_expr **out);
+qe_status qe_lit_int(int32_t value, qe_logical_expr **out);
+qe_status qe_lit_int64(int64_t value, qe_logical_expr **out);
+qe_status qe_lit_float(double value, qe_logical_expr **out);
+qe_status qe_lit_bool(int32_t value, qe_logical_expr **out);
+/* LogicalExpression::{Eq..Or, Add..Mod} (logical_expression.rs:284-342) and the
+ * LogicalExpressionMethods (:425-472); op is a QE_OP_*.  Consumes both operands. */
+qe_status qe_logical_binary(int32_t op, qe_logical_expr *left, qe_logical_expr *right, qe_logical_expr **out);
+/* LogicalExpression::{Max, Min, Sum, Count, Avg} (logical_expression.rs:386-423,
+ * prelude.rs:27-33); kind is a QE_AGG_*.  Consumes expr. */
+qe_status qe_logical_aggregate(int32_t kind, qe_logical_expr *expr, qe_logical_expr **out);
+/* impl Display for LogicalExpression (logical_expression.rs:68-96). */
+qe_status qe_logical_expr_to_string(const qe_logical_expr *expr, char *buf, int64_t buf_len, int64_t *needed);
+void qe_logical_expr_free(qe_logical_expr *expr);
+
+/* DataFrame::parquet (dataframe.rs:38-41) with the file already decoded: a scan
+ * over device-resident batches whose columns carry the given names.  `label`
+ * stands where the path does in the plan's Display. */
+qe_status qe_dataframe_from_batches(qe_context *ctx, const char *label, const char *const *column_names, int32_t n_columns,
+                                    qe_batch *const *batches, int32_t n_batches, qe_dataframe **out);
+/* DataFrameTrait::{project, filter, aggregate} (dataframe.rs:44-69).  Each consumes
+ * `df` (also on failure) and the expressions.  An unknown column name fails with
+ * QE_ERR_NO_FIELD_IN_LOGICAL_PLAN (the reference panics while deriving the schema). */
+qe_status qe_dataframe_project(qe_dataframe *df, qe_logical_expr *const *exprs, int32_t n_exprs, qe_dataframe **out);
+qe_status qe_dataframe_filter(qe_dataframe *df, qe_logical_expr *expr, qe_dataframe **out);
+qe_status qe_dataframe_aggregate(qe_dataframe *df, qe_logical_expr *const *group_by, int32_t n_group_by,
+                                 qe_logical_expr *const *aggregate_expr, int32_t n_aggregate_expr, qe_dataframe **out);
+/* LogicalPlan::optimize = projection push-down (logical_plan/optimizer.rs:7-58).  Consumes df. */
+qe_status qe_dataframe_optimize(qe_dataframe *df, qe_dataframe **out);
+/* DataFrameTrait::schema (dataframe.rs:71-73) as JSON:
+ * [{"name":..,"data_type":"Int32"|..,"type":QE_TYPE_*,"is_nullable":bool}, ...] */
+qe_status qe_dataframe_schema(const qe_dataframe *df, char *buf, int64_t buf_len, int64_t *needed);
+/* format_logical_plan (logical_plan/mod.rs:48-58). */
+qe_status qe_dataframe_logical_plan(const qe_dataframe *df, char *buf, int64_t buf_len, int64_t *needed);
+/* LogicalPlan::to_physical_plan (query_planner.rs:104-166).  Consumes df. */
+qe_status qe_dataframe_to_physical_plan(qe_dataframe *df, qe_plan **out);
+/* DataFrame::execute (dataframe.rs:80-83).  Consumes df. */
+qe_status qe_dataframe_execute(qe_dataframe *df, qe_iter **out);
+void qe_dataframe_free(qe_dataframe *df);
+
 /* Introspection (no counterpart in the reference; needs no GPU): lowers
  *   Scan(schema) -> [Selection predicate] -> [Projection exprs] -> [Aggregate group_exprs, agg_exprs]
  * exactly as qe_plan_execute would and writes a JSON description of every

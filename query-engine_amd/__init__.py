@@ -96,6 +96,28 @@ ABI = {
                                        C.c_void_p]),
     "qe_context_profile": (C.c_int32, [C.c_void_p, C.c_int32]),
     "qe_context_profile_read": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "qe_col": (C.c_int32, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "qe_lit_string": (C.c_int32, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "qe_lit_int": (C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
+    "qe_lit_int64": (C.c_int32, [C.c_int64, C.POINTER(C.c_void_p)]),
+    "qe_lit_float": (C.c_int32, [C.c_double, C.POINTER(C.c_void_p)]),
+    "qe_lit_bool": (C.c_int32, [C.c_int32, C.POINTER(C.c_void_p)]),
+    "qe_logical_binary": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "qe_logical_aggregate": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "qe_logical_expr_to_string": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "qe_logical_expr_free": (None, [C.c_void_p]),
+    "qe_dataframe_from_batches": (C.c_int32, [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
+                                              C.POINTER(C.c_void_p)]),
+    "qe_dataframe_project": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]),
+    "qe_dataframe_filter": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "qe_dataframe_aggregate": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
+                                           C.POINTER(C.c_void_p)]),
+    "qe_dataframe_optimize": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "qe_dataframe_schema": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "qe_dataframe_logical_plan": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "qe_dataframe_to_physical_plan": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "qe_dataframe_execute": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "qe_dataframe_free": (None, [C.c_void_p]),
     "qe_lowering_describe": (C.c_int32, [C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_int32, C.c_uint32, C.c_void_p,
                                          C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
                                          C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_char_p, C.c_int64,
@@ -788,3 +810,7 @@ def compile_lowering(col_types, col_nullable=None, predicate=None, exprs=(), gro
     _lowering_call(lib.qe_lowering_compile, col_types, col_nullable, predicate, exprs, group_exprs, agg_exprs, mode, flags,
                    (C.byref(nk), C.byref(nb)))
     return nk.value, nb.value
+
+
+from .dataframe import DataFrame, LogicalExpression  # noqa: E402,F401
+from . import prelude  # noqa: E402,F401

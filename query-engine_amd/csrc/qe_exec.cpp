@@ -13,6 +13,7 @@
 
 #include "qe_core.h"
 #include "qe_jit.h"
+#include "qe_plan.h"
 
 namespace qe {
 
@@ -846,21 +847,6 @@ struct AggIter : Iter {
 };
 
 // -------------------------------------------------------------------- plans
-enum PlanKind { PK_SCAN = 0, PK_PROJECTION = 1, PK_SELECTION = 2, PK_AGGREGATE = 3 };
-
-struct Plan {
-  PlanKind kind = PK_SCAN;
-  Context *ctx = nullptr;
-  std::unique_ptr<Plan> child;
-  std::vector<Batch> batches;       // scan
-  std::vector<ExprPtr> exprs;       // projection
-  ExprPtr pred;                     // selection
-  std::vector<ExprPtr> group_exprs; // aggregate
-  std::vector<AggExpr> aggs;
-  int mode = QE_AGG_MODE_SINGLE;
-  int64_t cap_hint = 0;
-};
-
 static Stream build_stream(std::unique_ptr<Plan> plan) {
   Context *ctx = plan->ctx;
   switch (plan->kind) {
@@ -1121,6 +1107,15 @@ static qe_status write_string(const std::string &s, char *buf, int64_t buf_len, 
   }
   return QE_OK;
 }
+
+qe_status qe_guarded(const std::function<void()> &f) { return guarded(f); }
+void qe_write_string(const std::string &s, char *buf, int64_t buf_len, int64_t *needed) { (void)write_string(s, buf, buf_len, needed); }
+const qe::Batch &qe_batch_ref(const qe_batch *batch) {
+  if (!batch) fail(QE_ERR_INVALID_ARGUMENT, "batch is null");
+  return batch->b;
+}
+qe::Context *qe_context_ref(qe_context *ctx) { return &ctx->c; }
+qe_plan *qe_plan_wrap(std::unique_ptr<qe::Plan> plan) { return new qe_plan{std::move(plan)}; }
 
 extern "C" {
 

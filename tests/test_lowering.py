@@ -76,3 +76,13 @@ def test_runtime_compilation_offline(qe):
     assert qe.compile_lowering([utf8, i32], exprs=[qe.EqExpression(C(0), C(0))]) == (0, 0)
     d = qe.describe_lowering([utf8, i32], exprs=[qe.EqExpression(C(0), C(0))])
     assert d["launches"][0]["specialisable"] == 0
+
+
+def test_logical_expression_display(qe):
+    """impl Display for LogicalExpression (logical_expression.rs:68-96, 123-127, 276-280, 378-382)."""
+    P = qe.prelude
+    assert str(P.col("gender").eq(P.lit_string("Female"))) == "#gender == 'Female'"
+    assert str(P.max(P.col("salary"))) == "max (#salary)"
+    assert str(P.col("a") + P.col("b") * P.lit_float(0.5)) == "#a + #b * '0.5'"
+    assert str(P.lit_int(7).lteq(P.col("x")).and_(P.lit_bool(True))) == "'7' <= #x && 'true'"
+    assert str(P.count(P.col("id") % P.lit_int64(3))) == "count (#id % '3')"
