@@ -117,22 +117,29 @@ def main():
         proj = qe.ProjectionExec([sel], [C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
         return qe.AggregateExec([proj], [C(0)], aggs(1), mode=mode, group_capacity_hint=hint)
 
-    # partial tables (key:int64, sum:float64, count:int64) exchanged through fixed-size buffers
+    # partial tables (key:int64, sum:float64, count:int64).  Few groups: every rank gets every table
+    # (fixed-size all-gather) and merges them all.  Many groups: rows travel to the rank that owns their
+    # key (all-to-all), each rank merges its share, the result is the concatenation over the ranks.
     max_g = max(64, 2 * args.groups)
+    partitioned = args.groups > 65536
     if world > 1:
         from importlib import import_module
-        xch = import_module("query-engine_amd.distributed").PartialExchange(
-            torch, dist, xdev, world, max_g, [torch.int64, torch.float64, torch.int64])
+        D = import_module("query-engine_amd.distributed")
+        layout = [torch.int64, torch.float64, torch.int64]
+        xch = D.KeyPartitionedExchange(torch, dist, xdev, world, layout) if partitioned else D.PartialExchange(torch, dist, xdev, world, max_g, layout)
 
     def step():
         part = list(local_plan().execute())[0]
         if world == 1:
             return part
         cols = [column_as_tensor(torch, part.column_desc(i), qe) for i in range(3)]
-        # the only collective of the plan: all-gather of the partial tables over xGMI
-        tables = xch.exchange(cols)
+        # the only collective of the plan: the exchange of the partial tables over xGMI
+        if partitioned:
+            tables = [xch.exchange(cols)]
+        else:
+            tables = xch.exchange(cols)
         parts = [qe.Batch.from_torch(ctx, [c.to(dev) for c in t]) for t in tables if t[0].shape[0] > 0]
-        final = qe.final_plan(qe.ScanExec(ctx, parts), 1, aggs(1), group_capacity_hint=hint)
+        final = qe.final_plan(qe.ScanExec(ctx, parts), 1, aggs(1), group_capacity_hint=hint if not partitioned else max(64, 2 * args.groups // world))
         return list(final.execute())[0]
 
     def barrier():
@@ -185,7 +192,8 @@ def main():
         "config": {"workload": "C5: Scan->Selection(c>0.5)->Projection(k, a+b*c)->Aggregate(GROUP BY k; SUM, COUNT)",
                    "rows_total": total, "rows_per_gpu": n, "groups": args.groups, "batch_rows": args.batch_rows,
                    "bytes_per_row": BYTES_PER_ROW["c5"], "partitioning": f"row-range x{world}",
-                   "merge": f"{'rccl' if backend == 'nccl' else backend} all_gather + FINAL aggregate" if world > 1 else "none"},
+                   "merge": (f"{'rccl' if backend == 'nccl' else backend} " + ("all_to_all by key owner" if partitioned else "all_gather") +
+                             " + FINAL aggregate") if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kname,
                      "avg_launch_ms": avg_ms, "rows_per_launch": rows_per_launch},
@@ -193,11 +201,15 @@ def main():
         "kernels": prof,
     }
 
+    groups_here = torch.tensor([result.num_rows, 0], dtype=torch.int64, device=xdev)
+    cols = result.columns()
+    groups_here[1] = int(cols[2].values.sum())
+    if world > 1 and partitioned:
+        dist.all_reduce(groups_here)  # every rank holds a share of the groups
     if rank == 0:
-        cols = result.columns()
         order = np.argsort(cols[0].values)
-        out["result_groups"] = int(result.num_rows)
-        out["result_count_total"] = int(cols[2].values.sum())
+        out["result_groups"] = int(groups_here[0])
+        out["result_count_total"] = int(groups_here[1])
         out["result_head"] = [[int(cols[0].values[i]), float(cols[1].values[i]), int(cols[2].values[i])] for i in order[:3]]
 
     if world == 1 and not args.no_extra:

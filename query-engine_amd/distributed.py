@@ -62,3 +62,51 @@ class PartialExchange:
 def shard_range(total_rows, rank, world):
     """Contiguous row range of `rank`: concatenating the ranges in rank order gives the table."""
     return rank * total_rows // world, (rank + 1) * total_rows // world
+
+
+class KeyPartitionedExchange:
+    """Exchange for partial tables too large to replicate (about a million groups): every partial row
+    goes to the rank that owns its key (hash of the first column modulo the number of ranks) with one
+    all-to-all, each rank merges only its share of the key space, and the result is the concatenation
+    of the ranks' outputs.  Per rank (W - 1) / W of its table crosses the links once, spread over all
+    peers at the same time (xGMI is point to point: W - 1 direct transfers of 1 / W each), instead of
+    W tables arriving at every rank as in an all-gather.
+
+    Columns are int64 or float64; they travel as one [rows, columns] int64 matrix (float64 bit patterns
+    reinterpreted), so a step costs one small all-to-all of row counts and one of payload."""
+
+    def __init__(self, torch, dist, device, world, dtypes):
+        self.torch, self.dist, self.device, self.world = torch, dist, device, world
+        self.dtypes = list(dtypes)
+        for d in self.dtypes:
+            if d not in (torch.int64, torch.float64):
+                raise ValueError("partial tables hold int64 and float64 columns only")
+        self.send_counts = torch.zeros(world, dtype=torch.int64, device=device)
+        self.recv_counts = torch.zeros(world, dtype=torch.int64, device=device)
+
+    def owner(self, keys):
+        """Rank that merges each key (int64 tensor): multiplicative hash, high bits, modulo ranks."""
+        h = (keys * -7046029254386353131) >> 17  # wraps; arithmetic shift
+        return (h & 0x7FFFFFFF) % self.world
+
+    def exchange(self, columns):
+        """columns: this rank's partial table (column 0 = int64 key).  Returns the rows this rank owns,
+        from all ranks, as a list of column tensors (freshly allocated)."""
+        torch = self.torch
+        if len(columns) != len(self.dtypes):
+            raise ValueError("column count differs from the exchange layout")
+        rows = int(columns[0].shape[0])
+        payload = torch.empty((rows, len(columns)), dtype=torch.int64, device=self.device)
+        for i, c in enumerate(columns):
+            payload[:, i] = c.to(self.device).view(torch.int64) if c.dtype == torch.float64 else c.to(self.device)
+        dest = self.owner(payload[:, 0])
+        order = torch.argsort(dest, stable=True)
+        payload = payload[order].contiguous()
+        self.send_counts.copy_(torch.bincount(dest, minlength=self.world))
+        self.dist.all_to_all_single(self.recv_counts, self.send_counts)
+        send = self.send_counts.tolist()
+        recv = self.recv_counts.tolist()
+        out = torch.empty((sum(recv), len(columns)), dtype=torch.int64, device=self.device)
+        self.dist.all_to_all_single(out, payload, output_split_sizes=recv, input_split_sizes=send)
+        return [out[:, i].contiguous().view(torch.float64) if d == torch.float64 else out[:, i].contiguous()
+                for i, d in enumerate(self.dtypes)]

@@ -76,6 +76,60 @@ def test_two_rank_partial_exchange(tmp_path, n, n_keys):
             assert abs(got["s"][i] - v[sel].sum()) <= 1e-12 * np.abs(v[sel]).sum()
 
 
+def _worker_partitioned(rank, world, port, n, n_keys, out_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as orc
+    d = importlib.import_module("query-engine_amd.distributed")
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        r = np.random.default_rng(9)
+        k = r.integers(-n_keys // 2, n_keys // 2, n).astype(np.int64) * 1_000_003
+        v = r.uniform(-1, 1, n)
+        lo, hi = d.shard_range(n, rank, world)
+        C = orc.ColumnExpression
+        chunk = orc.Chunk([orc.Array(orc.INT64, k[lo:hi]), orc.Array(orc.FLOAT64, v[lo:hi])])
+        part = list(orc.AggregateExec([orc.ScanExec([chunk])], [C(0)], [orc.SumExpression(C(1)), orc.CountExpression(None)]).execute())[0]
+        cols = [torch.from_numpy(np.ascontiguousarray(x.values)) for x in part.arrays]
+        xch = d.KeyPartitionedExchange(torch, dist, "cpu", world, [torch.int64, torch.float64, torch.int64])
+        for _ in range(2):
+            mine = xch.exchange(cols)
+        assert (xch.owner(mine[0]) == rank).all()  # only keys this rank owns arrived
+        merged = list(orc.AggregateExec([orc.ScanExec([orc.Chunk([orc.Array(orc.INT64, mine[0].numpy().copy()),
+                                                                    orc.Array(orc.FLOAT64, mine[1].numpy().copy()),
+                                                                    orc.Array(orc.INT64, mine[2].numpy().copy())])])],
+                                        [C(0)], [orc.SumExpression(C(1)), orc.SumExpression(C(2))]).execute())[0]
+        np.savez(os.path.join(out_dir, f"part{rank}.npz"), k=merged.arrays[0].values, s=merged.arrays[1].values, c=merged.arrays[2].values)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_key_partitioned_exchange(tmp_path):
+    """High-cardinality merge: partial tables are split by key owner with one all-to-all; the ranks'
+    merged shares are disjoint and together equal the aggregate of the whole table."""
+    import torch.multiprocessing as mp
+    world, port, n, n_keys = 2, _free_port(), 60_000, 20_000
+    mp.spawn(_worker_partitioned, args=(world, port, n, n_keys, str(tmp_path)), nprocs=world, join=True)
+    r = np.random.default_rng(9)
+    k = r.integers(-n_keys // 2, n_keys // 2, n).astype(np.int64) * 1_000_003
+    v = r.uniform(-1, 1, n)
+    parts = [np.load(tmp_path / f"part{rank}.npz") for rank in range(world)]
+    keys = np.concatenate([p["k"] for p in parts])
+    assert len(set(keys.tolist())) == len(keys) == len(np.unique(k))  # disjoint shares, complete
+    assert min(len(p["k"]) for p in parts) > 0.3 * len(keys)           # and roughly balanced
+    order = np.argsort(keys)
+    uk, inv = np.unique(k, return_inverse=True)
+    assert np.array_equal(keys[order], uk)
+    assert np.array_equal(np.concatenate([p["c"] for p in parts])[order], np.bincount(inv))
+    sums = np.concatenate([p["s"] for p in parts])[order]
+    ref = np.bincount(inv, weights=v)
+    scale = np.bincount(inv, weights=np.abs(v))
+    assert (np.abs(sums - ref) <= 1e-12 * np.maximum(scale, 1e-300)).all()
+
+
 def test_exchange_rejects_oversized_table():
     import torch
     d = importlib.import_module("query-engine_amd.distributed")
