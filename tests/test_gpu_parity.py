@@ -428,3 +428,15 @@ def test_utf8_group_key(qe, ctx):
         list(qe.AggregateExec([qe.ScanExec(ctx, [gpu_batch(qe, ctx, arrays)])], [qe.ColumnExpression(ci), qe.ColumnExpression(COL["id"])],
                               [qe.MaxExpression(qe.ColumnExpression(si))]).execute())
     assert e.value.name == "PhysicalTypeNotSuported"
+
+
+def test_c_abi_from_plain_c():
+    """examples/abi_example.c: the headline plan built and run through the C ABI from C alone (no Python in
+    the process), checked against a CPU evaluation inside the program."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "bin", "abi_example")
+    assert os.path.exists(exe), "build it with python query-engine_amd/build.py"
+    r = subprocess.run([exe, "3000001"], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "C ABI example ok" in r.stdout and "Aggregate:" in r.stdout
