@@ -910,16 +910,18 @@ constexpr int LEADER_TRIES = 2;
 
 // ------------------------------------------------------------ aggregate sink
 // Shared by the interpreted and the statically specialised aggregate kernels.
+// `with_nn` = false leaves out the per-accumulator counts of valid inputs (nobody tracks them in
+// the partition-wise aggregate), which makes room for a third more slots.
 __device__ __forceinline__ void agg_lds_setup(LdsTable &L, unsigned long long *lds_raw, uint32_t lds_cap, uint32_t lds_limit,
-                                              int n_accs) {
+                                              int n_accs, bool with_nn = true) {
   L.cap = lds_cap;
   L.stride = lds_cap + 1;
   L.limit = lds_limit;
   L.keys = lds_raw;
   L.acc = L.keys + L.stride;
   L.rowcnt = (uint32_t *)(L.acc + (size_t)n_accs * L.stride);
-  L.nn = L.rowcnt + L.stride;
-  L.used = L.nn + (size_t)n_accs * L.stride;
+  L.nn = with_nn ? L.rowcnt + L.stride : nullptr;
+  L.used = L.rowcnt + L.stride + (with_nn ? (size_t)n_accs * L.stride : 0);
 }
 
 struct AggRows {
@@ -1177,7 +1179,7 @@ __device__ __forceinline__ void agg_flush(const LdsTable &L, const AggTable &T, 
       uint32_t op = accs[a].op;
       unsigned long long val = L.acc[a * L.stride + i];
       if (val != acc_identity(op) || op == ACC_SUM_F64) acc_apply(&T.acc[(uint64_t)a * T.stride + g], op, val);
-      uint32_t nn = L.nn[a * L.stride + i];
+      uint32_t nn = L.nn ? L.nn[a * L.stride + i] : 0u;
       if (nn) atomicAdd(&T.nn[(uint64_t)a * T.stride + g], (unsigned long long)nn);
     }
   }
@@ -1189,7 +1191,7 @@ __device__ __forceinline__ void agg_lds_clear(const LdsTable &L, const VmAcc *ac
     L.rowcnt[i] = 0;
     for (int a = 0; a < n_accs; ++a) {
       L.acc[a * L.stride + i] = acc_identity(accs[a].op);
-      L.nn[a * L.stride + i] = 0;
+      if (L.nn) L.nn[a * L.stride + i] = 0;
     }
   }
   if (threadIdx.x == 0) *L.used = 0;

@@ -651,11 +651,16 @@ static SpillPlan plan_spill(Context *ctx, const AggSpec &bspec, AggArgs &args, i
 
 // Second phase: partition the log by key hash, aggregate partition by partition.
 static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &args, int64_t group_hint) {
-  // partitions: up to 1280 distinct keys each, which the LDS table of the second phase (at least 2048
-  // slots, filled to three quarters) holds; fewer partitions mean deeper stages in the move
+  // partitions: as few as keep a partition's distinct keys within 5/8 of the LDS table of the second
+  // phase (fewer partitions mean deeper stages and longer bursts in the move)
+  const int64_t keys_per_partition = (int64_t)partitioned_lds_slots(args.n_accs) * 5 / 8;
   int bits = 6;
-  while (bits < 11 && ((int64_t)1 << bits) * 1280 < group_hint) ++bits;
-  const int blocks = ctx->dev.cus;
+  while (bits < 11 && ((int64_t)1 << bits) * keys_per_partition < group_hint) ++bits;
+  static int forced_blocks = [] {
+    const char *e = getenv("QE_SPILL_BLOCKS");
+    return e ? atoi(e) : 0;
+  }();
+  const int blocks = forced_blocks > 0 ? forced_blocks : ctx->dev.cus;
   const size_t cells = spill_cells(bits, blocks);
   BufferPtr cell_buf = device_buffer(ctx, (cells + 1) * 4 + 64);
   BufferPtr scan_buf = device_buffer(ctx, scan_scratch_elems((int64_t)cells) * 4 + 64);

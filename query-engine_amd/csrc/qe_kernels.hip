@@ -258,13 +258,14 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_partition_kernel(AggSpi
 // a different cache line (partitions x workgroups of them are open at once, far more than L2 holds),
 // and the partial lines are written back again and again.  Here a workgroup collects up to S rows per
 // partition in LDS and writes them as one burst, eight lanes to a burst; rows that find their
-// partition's stage full are written directly (rare: a stage is emptied as soon as it is three
-// quarters full).  The next round's rows are loaded before the current round is staged, so the
-// barriers of a round do not leave the memory pipeline empty.
+// partition's stage full are written directly (rare).  A thread handles up to MOVE_ROWS rows per
+// round with all their loads issued together, and every non-empty stage is flushed each round.
 // Dynamic LDS: keys[P * S], then vals[n_inputs][P * S].
-constexpr int MOVE_MAX_INPUTS = 8;
+constexpr int MOVE_MAX_INPUTS = 4;
+constexpr int MOVE_ROWS = 4;
 
-__global__ __launch_bounds__(PART_THREADS) void qe_spill_move_staged_kernel(AggSpill sp, int n_segments, int bits, int S, const int32_t *cells,
+__global__ __launch_bounds__(PART_THREADS) void qe_spill_move_staged_kernel(AggSpill sp, int n_segments, int bits, int S, int rows_per_thread,
+                                                                            const int32_t *cells,
                                                                             unsigned long long *out_keys, unsigned long long *out_vals) {
   extern __shared__ unsigned long long lds_stage[];
   __shared__ uint32_t s_cur[1 << PART_MAX_BITS];    // next output row of each partition (this workgroup's cell)
@@ -306,61 +307,50 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_move_staged_kernel(AggS
     if (threadIdx.x == 0) s_nready = 0;
   };
 
-  // (segment, offset) of the round in flight and of the one being loaded; uniform over the workgroup
-  int seg = blockIdx.x;
-  uint32_t i0 = 0;
-  uint32_t cnt = 0;
-  while (seg < n_segments && (cnt = sp.counts[seg]) == 0) seg += gridDim.x;
-  bool have = false;
-  unsigned long long key = 0, val[MOVE_MAX_INPUTS];
-  auto load_round = [&](int sg, uint32_t off, uint32_t c) {
-    const uint32_t i = off + threadIdx.x;
-    have = sg < n_segments && i < c;
-    if (have) {
-      const uint64_t r = (uint64_t)sg * sp.rows_per_wave + i;
-      key = sp.keys[r];
+  // A round = MOVE_ROWS rows per thread of one segment, all their loads in flight together; every
+  // stage that holds anything is written out at the end of the round, so a stage only has to take
+  // one round's rows of its partition (the host picks rows per round and stage depth to match).
+  for (int seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
+    const uint32_t cnt = sp.counts[seg];
+    const uint64_t base = (uint64_t)seg * sp.rows_per_wave;
+    for (uint32_t i0 = 0; i0 < cnt; i0 += blockDim.x * (uint32_t)rows_per_thread) {  // uniform trip count: barriers inside
+      unsigned long long key[MOVE_ROWS], val[MOVE_ROWS][MOVE_MAX_INPUTS];
+      bool have[MOVE_ROWS];
 #pragma unroll
-      for (int v = 0; v < MOVE_MAX_INPUTS; ++v)
-        if ((uint32_t)v < n_in) val[v] = sp.vals[(uint64_t)v * sp.capacity + r];
-    }
-  };
-  load_round(seg, i0, cnt);
-  const uint32_t flush_at = (uint32_t)(S - S / 4);
-  while (seg < n_segments) {
-    // this round's rows are in registers; advance and start loading the next round's
-    const bool cur_have = have;
-    const unsigned long long cur_key = key;
-    unsigned long long cur_val[MOVE_MAX_INPUTS];
+      for (int r = 0; r < MOVE_ROWS; ++r) {
+        const uint32_t i = i0 + (uint32_t)r * blockDim.x + threadIdx.x;
+        have[r] = r < rows_per_thread && i < cnt;
+        if (have[r]) {
+          key[r] = sp.keys[base + i];
 #pragma unroll
-    for (int v = 0; v < MOVE_MAX_INPUTS; ++v) cur_val[v] = val[v];
-    i0 += blockDim.x;
-    if (i0 >= cnt) {
-      i0 = 0;
-      seg += gridDim.x;
-      while (seg < n_segments && (cnt = sp.counts[seg]) == 0) seg += gridDim.x;
-    }
-    load_round(seg, i0, cnt);
-    if (cur_have) {
-      const uint32_t p = partition_of(cur_key, bits);
-      const uint32_t slot = atomicAdd(&s_cnt[p], 1u);
-      if (slot < (uint32_t)S) {
-        st_keys[(size_t)p * S + slot] = cur_key;
-#pragma unroll
-        for (int v = 0; v < MOVE_MAX_INPUTS; ++v)
-          if ((uint32_t)v < n_in) st_vals[((size_t)v * P + p) * S + slot] = cur_val[v];
-      } else {
-        const uint32_t pos = atomicAdd(&s_cur[p], 1u);  // stage full: straight to memory
-        out_keys[pos] = cur_key;
-#pragma unroll
-        for (int v = 0; v < MOVE_MAX_INPUTS; ++v)
-          if ((uint32_t)v < n_in) out_vals[(uint64_t)v * sp.capacity + pos] = cur_val[v];
+          for (int v = 0; v < MOVE_MAX_INPUTS; ++v)
+            if ((uint32_t)v < n_in) val[r][v] = sp.vals[(uint64_t)v * sp.capacity + base + i];
+        }
       }
+#pragma unroll
+      for (int r = 0; r < MOVE_ROWS; ++r) {
+        if (have[r]) {
+          const uint32_t p = partition_of(key[r], bits);
+          const uint32_t slot = atomicAdd(&s_cnt[p], 1u);
+          if (slot < (uint32_t)S) {
+            st_keys[(size_t)p * S + slot] = key[r];
+#pragma unroll
+            for (int v = 0; v < MOVE_MAX_INPUTS; ++v)
+              if ((uint32_t)v < n_in) st_vals[((size_t)v * P + p) * S + slot] = val[r][v];
+          } else {
+            const uint32_t pos = atomicAdd(&s_cur[p], 1u);  // stage full: straight to memory
+            out_keys[pos] = key[r];
+#pragma unroll
+            for (int v = 0; v < MOVE_MAX_INPUTS; ++v)
+              if ((uint32_t)v < n_in) out_vals[(uint64_t)v * sp.capacity + pos] = val[r][v];
+          }
+        }
+      }
+      __syncthreads();
+      flush(1);
+      __syncthreads();
     }
-    __syncthreads();
-    flush(flush_at);
-    __syncthreads();
   }
-  flush(1);
 }
 
 // One ticket = one partition: all its rows folded into a fresh LDS table, the table flushed into
@@ -372,7 +362,7 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t n_waves = blockDim.x >> 6;
   LdsTable L;
-  agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, A.n_accs);
+  agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, A.n_accs, false);
   SpillState none;
   none.keys = nullptr;
   none.vals = nullptr;
@@ -728,9 +718,9 @@ hipError_t launch_filter(const FilterArgs &args, const DeviceInfo &dev, hipStrea
   return hipGetLastError();
 }
 
-static size_t agg_lds_bytes(int n_accs, uint32_t slots) {
+static size_t agg_lds_bytes(int n_accs, uint32_t slots, bool with_nn = true) {
   size_t stride = (size_t)slots + 1;
-  return stride * 8 + stride * 8 * n_accs + stride * 4 + stride * 4 * n_accs + 16;
+  return stride * 8 + stride * 8 * n_accs + stride * 4 + (with_nn ? stride * 4 * n_accs : 0) + 16;
 }
 
 // LDS table slots.  A table much larger than the number of groups only costs occupancy (with a
@@ -796,17 +786,22 @@ hipError_t launch_spill_partition(const AggSpill &sp, int n_segments, int bits, 
   if (move) {
     // stage depth from what 120 KiB of LDS hold; shallow stages are not worth their barriers
     const size_t row_bytes = 8 * (1 + (size_t)sp.n_inputs);
-    int S = (int)((size_t)120 * 1024 / (((size_t)1 << bits) * row_bytes));
-    if (S > 16) S = 16;
-    if (S >= 4) {
+    const int P = 1 << bits;
+    int S = (int)((size_t)120 * 1024 / ((size_t)P * row_bytes));
+    if (S > 32) S = 32;
+    // rows per thread and round: a round brings rows_per_thread * 1024 / P rows to a partition on
+    // average; keep that at half the stage depth or less, so that overflowing stages stay rare
+    int rows_per_thread = (int)((int64_t)S * P / (2 * PART_THREADS));
+    if (rows_per_thread > MOVE_ROWS) rows_per_thread = MOVE_ROWS;
+    if (S >= 4 && rows_per_thread >= 1 && sp.n_inputs <= (uint32_t)MOVE_MAX_INPUTS) {
       static bool attr_set = false;
       if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)qe_spill_move_staged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
       }
-      hipLaunchKernelGGL(qe_spill_move_staged_kernel, dim3(blocks), dim3(PART_THREADS), ((size_t)1 << bits) * S * row_bytes, stream, sp,
-                         n_segments, bits, S, cells, out_keys, out_vals);
+      hipLaunchKernelGGL(qe_spill_move_staged_kernel, dim3(blocks), dim3(PART_THREADS), (size_t)P * S * row_bytes, stream, sp, n_segments, bits,
+                         S, rows_per_thread, cells, out_keys, out_vals);
     } else {
       hipLaunchKernelGGL(qe_spill_partition_kernel<true>, dim3(blocks), dim3(PART_THREADS), 0, stream, sp, n_segments, bits, cells, out_keys,
                          out_vals, total);
@@ -821,15 +816,15 @@ hipError_t launch_spill_partition(const AggSpill &sp, int n_segments, int bits, 
 // LDS slots of the partition-wise aggregate: as many as 144 KiB hold (one workgroup per compute unit).
 uint32_t partitioned_lds_slots(int n_accs) {
   uint32_t slots = 8192;
-  while (slots > 64 && agg_lds_bytes(n_accs, slots) > (size_t)144 * 1024) slots >>= 1;
+  while (slots > 64 && agg_lds_bytes(n_accs, slots, false) > (size_t)148 * 1024) slots >>= 1;
   return slots;
 }
 
 hipError_t launch_aggregate_partitioned(const PartArgs &args, const DeviceInfo &dev, hipStream_t stream) {
-  size_t lds = agg_lds_bytes(args.n_accs, args.lds_cap);
+  size_t lds = agg_lds_bytes(args.n_accs, args.lds_cap, false);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)qe_aggregate_partitioned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void *)qe_aggregate_partitioned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
