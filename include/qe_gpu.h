@@ -61,13 +61,18 @@ enum {
 
 /* Column element types.  INT32/FLOAT64/UTF8/BOOLEAN are the four the
  * reference's ColumnExpression accepts (physical_expressions.rs:37-60);
- * INT64 is the extension the north-star configs use. */
+ * INT64 is the extension the north-star configs use.  TIMESTAMP_NS (int64
+ * nanoseconds since the epoch, arrow's Timestamp(Nanosecond, None)) is what
+ * the Parquet scan yields for INT96 columns (tests/mod.rs:31): such a column
+ * passes through scans and selections, but no expression computes on it (the
+ * reference's ColumnExpression rejects it the same way). */
 enum {
   QE_TYPE_INT32 = 1,
   QE_TYPE_INT64 = 2,
   QE_TYPE_FLOAT64 = 3,
   QE_TYPE_BOOLEAN = 4,
-  QE_TYPE_UTF8 = 5
+  QE_TYPE_UTF8 = 5,
+  QE_TYPE_TIMESTAMP_NS = 6
 };
 
 enum { QE_MEM_HOST = 0, QE_MEM_DEVICE = 1 };
@@ -214,6 +219,21 @@ void qe_agg_expr_free(qe_agg_expr *agg);
  * schema) stands (physical_plan/mod.rs:68-110); yields the given batches in
  * order.  The plan shares (does not copy) the batches' buffers. */
 qe_status qe_plan_scan_memory(qe_context *ctx, qe_batch *const *batches, int32_t n_batches, qe_plan **out);
+/* Parquet scan leaf: ScanExec::new(DataSource::Parquet(ParquetDataSource::new(path)),
+ * projection, schema) (physical_plan/mod.rs:68-110, data_source.rs:24-72).  Yields
+ * one device-resident batch per row group, holding the columns whose names
+ * `projection` lists, in file order (n_projection < 0: every column, the
+ * reference's `None`).  The file's bytes are decoded on the GPU; the host reads
+ * the footer and the page headers only.  QE_ERR_IO when the file cannot be
+ * opened (Error::IoError), QE_ERR_ARROW when it is not a Parquet file or uses a
+ * feature this reader lacks (nested schemas, delta encodings, LZO / Brotli),
+ * QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED at execution when a scanned column has a
+ * type outside QE_TYPE_*. */
+qe_status qe_plan_scan_parquet(qe_context *ctx, const char *path, const char *const *projection, int32_t n_projection, qe_plan **out);
+/* ParquetDataSource::schema (data_source.rs:45-47) as JSON, in the format of
+ * qe_dataframe_schema, plus "rows" and "row_groups":
+ * {"fields":[...],"rows":N,"row_groups":G}.  Needs no GPU. */
+qe_status qe_parquet_schema(const char *path, char *buf, int64_t buf_len, int64_t *needed);
 /* ProjectionExec::new(input, exprs, schema) (physical_plan/mod.rs:118-130).
  * Consumes `child` and the expressions. */
 qe_status qe_plan_projection(qe_plan *child, qe_expr *const *exprs, int32_t n_exprs, qe_plan **out);
@@ -281,6 +301,10 @@ qe_status qe_logical_aggregate(int32_t kind, qe_logical_expr *expr, qe_logical_e
 qe_status qe_logical_expr_to_string(const qe_logical_expr *expr, char *buf, int64_t buf_len, int64_t *needed);
 void qe_logical_expr_free(qe_logical_expr *expr);
 
+/* DataFrame::parquet(path) (dataframe.rs:38-41): a scan of a Parquet file (see
+ * qe_plan_scan_parquet).  Projection push-down (qe_dataframe_optimize) narrows
+ * what is read from the file. */
+qe_status qe_dataframe_parquet(qe_context *ctx, const char *path, qe_dataframe **out);
 /* DataFrame::parquet (dataframe.rs:38-41) with the file already decoded: a scan
  * over device-resident batches whose columns carry the given names.  `label`
  * stands where the path does in the plan's Display. */

@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libqe_gpu.so")
 
 # ---- constants (include/qe_gpu.h)
 QE_OK, QE_END = 0, 1
-TYPE_INT32, TYPE_INT64, TYPE_FLOAT64, TYPE_BOOLEAN, TYPE_UTF8 = 1, 2, 3, 4, 5
+TYPE_INT32, TYPE_INT64, TYPE_FLOAT64, TYPE_BOOLEAN, TYPE_UTF8, TYPE_TIMESTAMP_NS = 1, 2, 3, 4, 5, 6
 MEM_HOST, MEM_DEVICE = 0, 1
 OP_EQ, OP_NEQ, OP_GT, OP_GTEQ, OP_LT, OP_LTEQ, OP_AND, OP_OR, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MOD = range(1, 14)
 AGG_MAX, AGG_MIN, AGG_SUM, AGG_COUNT, AGG_AVG = 1, 2, 3, 4, 5
@@ -34,7 +34,7 @@ FLAG_REFERENCE_SCALAR_ARRAY_SWAP = 1
 FLAG_NO_SPECIALIZED_KERNELS = 2
 FLAG_JIT_SYNC = 4
 
-_NP_OF_TYPE = {TYPE_INT32: np.int32, TYPE_INT64: np.int64, TYPE_FLOAT64: np.float64}
+_NP_OF_TYPE = {TYPE_INT32: np.int32, TYPE_INT64: np.int64, TYPE_FLOAT64: np.float64, TYPE_TIMESTAMP_NS: np.int64}
 _TYPE_OF_NP = {np.dtype(np.int32): TYPE_INT32, np.dtype(np.int64): TYPE_INT64, np.dtype(np.float64): TYPE_FLOAT64,
                np.dtype(np.bool_): TYPE_BOOLEAN}
 
@@ -82,6 +82,8 @@ ABI = {
     "qe_agg_expr_new": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "qe_agg_expr_free": (None, [C.c_void_p]),
     "qe_plan_scan_memory": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]),
+    "qe_plan_scan_parquet": (C.c_int32, [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_void_p)]),
+    "qe_parquet_schema": (C.c_int32, [C.c_char_p, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
     "qe_plan_projection": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]),
     "qe_plan_selection": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "qe_plan_aggregate": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
@@ -106,6 +108,7 @@ ABI = {
     "qe_logical_aggregate": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "qe_logical_expr_to_string": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
     "qe_logical_expr_free": (None, [C.c_void_p]),
+    "qe_dataframe_parquet": (C.c_int32, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "qe_dataframe_from_batches": (C.c_int32, [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int32,
                                               C.POINTER(C.c_void_p)]),
     "qe_dataframe_project": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]),
@@ -669,6 +672,34 @@ class ScanExec(PhysicalPlan):
         h = C.c_void_p()
         _check(lib.qe_plan_scan_memory(self.ctx._h, arr, len(self.batches), C.byref(h)))
         return h
+
+
+class ParquetScanExec(PhysicalPlan):
+    """ScanExec over DataSource::Parquet (physical_plan/mod.rs:68-110, data_source.rs:24-72): one
+    device-resident batch per row group; `projection` = column names (None = all), file order."""
+
+    def __init__(self, ctx, path, projection=None):
+        super().__init__(ctx, [])
+        self.path, self.projection = path, None if projection is None else list(projection)
+
+    def _build(self):
+        h = C.c_void_p()
+        if self.projection is None:
+            _check(lib.qe_plan_scan_parquet(self.ctx._h, self.path.encode(), None, -1, C.byref(h)))
+        else:
+            names = (C.c_char_p * max(1, len(self.projection)))(*[n.encode() for n in self.projection])
+            _check(lib.qe_plan_scan_parquet(self.ctx._h, self.path.encode(), names, len(self.projection), C.byref(h)))
+        return h
+
+
+def parquet_schema(path):
+    """ParquetDataSource::schema (data_source.rs:45-47): {"fields": [...], "rows": N, "row_groups": G}.  Needs no GPU."""
+    import json
+    need = C.c_int64()
+    _check(lib.qe_parquet_schema(path.encode(), None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value + 1)
+    _check(lib.qe_parquet_schema(path.encode(), buf, len(buf), None))
+    return json.loads(buf.value.decode())
 
 
 def _build_list(items):

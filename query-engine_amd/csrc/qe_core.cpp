@@ -141,6 +141,7 @@ int type_width(int type) {
     case QE_TYPE_INT32: return 4;
     case QE_TYPE_INT64: return 8;
     case QE_TYPE_FLOAT64: return 8;
+    case QE_TYPE_TIMESTAMP_NS: return 8;
     default: return 0;
   }
 }
@@ -152,6 +153,7 @@ const char *type_name(int type) {
     case QE_TYPE_FLOAT64: return "Float64";
     case QE_TYPE_BOOLEAN: return "Boolean";
     case QE_TYPE_UTF8: return "Utf8";
+    case QE_TYPE_TIMESTAMP_NS: return "Timestamp(Nanosecond, None)";
     default: return "Unknown";
   }
 }

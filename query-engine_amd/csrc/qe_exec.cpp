@@ -25,9 +25,18 @@ struct Iter {
 };
 
 struct ScanIter : Iter {
+  Context *ctx = nullptr;
   std::vector<Batch> batches;
+  std::shared_ptr<ParquetFile> parquet;  // when set: one batch per row group, decoded on demand
+  std::vector<int> parquet_columns;
   size_t cur = 0;
   bool next(Batch &out) override {
+    if (parquet) {
+      // ScanIterator::next (physical_plan/mod.rs:99-109) over the file reader's row groups
+      if (cur >= parquet->row_groups.size()) return false;
+      out = parquet_read_row_group(ctx, *parquet, (int)cur++, parquet_columns);
+      return true;
+    }
     if (cur >= batches.size()) return false;
     out = batches[cur++];
     return true;
@@ -247,7 +256,40 @@ static size_t lower_filter(Compiler &comp, const Schema &schema, const ExprPtr &
 // Evaluates `outputs` (expressions over `in`'s columns) for the rows of `in`
 // that satisfy `pred` (all rows when null).  ProjectionIterator::next
 // (physical_plan/mod.rs:138-156) and SelectionIterator::next (:205-229) fused.
+static bool mentions_column_of_type(const ExprPtr &e, const Batch &in, int type) {
+  if (!e) return false;
+  if (e->kind == EK_COLUMN) return e->index >= 0 && e->index < (int)in.cols.size() && in.cols[e->index].type == type;
+  return mentions_column_of_type(e->l, in, type) || mentions_column_of_type(e->r, in, type);
+}
+
+static Batch run_pipeline_typed(Context *ctx, const Batch &in, const std::vector<ExprPtr> &outputs_raw, const ExprPtr &pred_raw);
+
+// Timestamp columns only ever pass through (the reference's ColumnExpression would not even
+// hand them out, physical_expressions.rs:37-60): they travel as the 64-bit integers they are
+// and get their type back on the way out.
 static Batch run_pipeline(Context *ctx, const Batch &in, const std::vector<ExprPtr> &outputs_raw, const ExprPtr &pred_raw) {
+  bool any = false;
+  for (auto &c : in.cols) any = any || c.type == QE_TYPE_TIMESTAMP_NS;
+  if (!any) return run_pipeline_typed(ctx, in, outputs_raw, pred_raw);
+  if (mentions_column_of_type(pred_raw, in, QE_TYPE_TIMESTAMP_NS))
+    fail(QE_ERR_PRIMITIVE_TYPE_NOT_SUPPORTED, "Primitive type `Timestamp(Nanosecond, None)` is not supported.");
+  std::vector<bool> restore(outputs_raw.size(), false);
+  for (size_t i = 0; i < outputs_raw.size(); ++i) {
+    const ExprPtr &e = outputs_raw[i];
+    if (e->kind == EK_COLUMN) restore[i] = mentions_column_of_type(e, in, QE_TYPE_TIMESTAMP_NS);
+    else if (mentions_column_of_type(e, in, QE_TYPE_TIMESTAMP_NS))
+      fail(QE_ERR_PRIMITIVE_TYPE_NOT_SUPPORTED, "Primitive type `Timestamp(Nanosecond, None)` is not supported.");
+  }
+  Batch plain = in;
+  for (auto &c : plain.cols)
+    if (c.type == QE_TYPE_TIMESTAMP_NS) c.type = QE_TYPE_INT64;
+  Batch out = run_pipeline_typed(ctx, plain, outputs_raw, pred_raw);
+  for (size_t i = 0; i < restore.size(); ++i)
+    if (restore[i]) out.cols[i].type = QE_TYPE_TIMESTAMP_NS;
+  return out;
+}
+
+static Batch run_pipeline_typed(Context *ctx, const Batch &in, const std::vector<ExprPtr> &outputs_raw, const ExprPtr &pred_raw) {
   ctx->bind();
   const int64_t n = in.rows;
   Schema schema = schema_of(in);
@@ -857,7 +899,10 @@ static Stream build_stream(std::unique_ptr<Plan> plan) {
   switch (plan->kind) {
     case PK_SCAN: {
       auto it = std::make_unique<ScanIter>();
+      it->ctx = ctx;
       it->batches = std::move(plan->batches);
+      it->parquet = plan->parquet;
+      it->parquet_columns = plan->parquet_columns;
       Stream s;
       s.src = std::move(it);
       return s;
@@ -904,7 +949,15 @@ static std::string plan_to_string(const Plan *p, int indent) {
   std::ostringstream o;
   o << std::string(indent * 2, ' ');
   switch (p->kind) {
-    case PK_SCAN: o << "Scan: memory, batches=" << p->batches.size(); break;
+    case PK_SCAN:
+      if (p->parquet) {
+        o << "Scan: " << p->parquet->path << "; projection=[";
+        for (size_t i = 0; i < p->parquet_columns.size(); ++i) o << (i ? ", " : "") << p->parquet->columns[p->parquet_columns[i]].name;
+        o << "], row_groups=" << p->parquet->row_groups.size();
+      } else {
+        o << "Scan: memory, batches=" << p->batches.size();
+      }
+      break;
     case PK_PROJECTION: {
       o << "Projection: ";
       for (size_t i = 0; i < p->exprs.size(); ++i) o << (i ? ", " : "") << expr_to_string(p->exprs[i]);
@@ -1230,7 +1283,7 @@ qe_status qe_batch_import(qe_context *ctx, const qe_column *columns, int32_t n_c
     int64_t rows = n_columns ? columns[0].length : 0;
     for (int i = 0; i < n_columns; ++i) {
       const qe_column &c = columns[i];
-      if (c.type < QE_TYPE_INT32 || c.type > QE_TYPE_UTF8)
+      if (c.type < QE_TYPE_INT32 || c.type > QE_TYPE_TIMESTAMP_NS)
         fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "Physical type `" + std::to_string(c.type) + "` is not supported.");
       QE_REQUIRE(c.length >= 0, "negative length");
       if (c.length != rows)
@@ -1481,6 +1534,48 @@ qe_status qe_plan_scan_memory(qe_context *ctx, qe_batch *const *batches, int32_t
       p->batches.push_back(batches[i]->b);
     }
     *out = new qe_plan{std::move(p)};
+  });
+}
+
+qe_status qe_plan_scan_parquet(qe_context *ctx, const char *path, const char *const *projection, int32_t n_projection, qe_plan **out) {
+  return guarded([&] {
+    QE_REQUIRE(ctx && out && path && (projection || n_projection <= 0), "bad arguments");
+    auto p = std::make_unique<Plan>();
+    p->kind = PK_SCAN;
+    p->ctx = &ctx->c;
+    p->parquet = parquet_open(path);
+    if (n_projection < 0) {
+      for (size_t i = 0; i < p->parquet->columns.size(); ++i) p->parquet_columns.push_back((int)i);
+    } else {
+      std::vector<std::string> names;
+      for (int i = 0; i < n_projection; ++i) {
+        QE_REQUIRE(projection[i], "projection name is null");
+        names.push_back(projection[i]);
+      }
+      p->parquet_columns = parquet_project(*p->parquet, names);
+    }
+    *out = new qe_plan{std::move(p)};
+  });
+}
+
+qe_status qe_parquet_schema(const char *path, char *buf, int64_t buf_len, int64_t *needed) {
+  return guarded([&] {
+    QE_REQUIRE(path, "bad arguments");
+    auto f = parquet_open(path);
+    std::ostringstream o;
+    o << "{\"fields\":[";
+    for (size_t i = 0; i < f->columns.size(); ++i) {
+      const ParquetColumn &c = f->columns[i];
+      std::string name;
+      for (char ch : c.name) {
+        if (ch == '"' || ch == '\\') name += '\\';
+        name += ch;
+      }
+      o << (i ? "," : "") << "{\"name\":\"" << name << "\",\"data_type\":\"" << (c.type ? type_name(c.type) : ("Unsupported(" + c.type_text + ")").c_str())
+        << "\",\"type\":" << c.type << ",\"is_nullable\":" << (c.optional ? "true" : "false") << "}";
+    }
+    o << "],\"rows\":" << f->num_rows << ",\"row_groups\":" << f->row_groups.size() << "}";
+    qe_write_string(o.str(), buf, buf_len, needed);
   });
 }
 

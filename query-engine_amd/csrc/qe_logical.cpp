@@ -133,6 +133,7 @@ struct LogicalPlan {
   std::string path;
   Fields source_schema;
   std::vector<Batch> batches;
+  std::shared_ptr<ParquetFile> parquet;  // a file instead of batches
   bool has_projection = false;
   std::vector<std::string> projection;
   // projection / selection / aggregate
@@ -140,13 +141,14 @@ struct LogicalPlan {
   std::vector<LogicalPtr> group_exprs, aggregate_exprs;
 };
 
-static LogicalPlanPtr make_scan(const std::string &path, const Fields &source_schema, const std::vector<Batch> &batches, bool has_projection,
-                                const std::vector<std::string> &projection) {
+static LogicalPlanPtr make_scan(const std::string &path, const Fields &source_schema, const std::vector<Batch> &batches,
+                                const std::shared_ptr<ParquetFile> &parquet, bool has_projection, const std::vector<std::string> &projection) {
   auto p = std::make_shared<LogicalPlan>();
   p->kind = LP_SCAN;
   p->path = path;
   p->source_schema = source_schema;
   p->batches = batches;
+  p->parquet = parquet;
   p->has_projection = has_projection;
   p->projection = projection;
   // derive_schema (logical_plan/mod.rs:79-91): the source's fields the projection names, in source order
@@ -220,7 +222,7 @@ static LogicalPlanPtr push_down(const LogicalPlanPtr &p, std::set<std::string> &
   switch (p->kind) {
     case LP_SCAN: {
       if (p->has_projection) cols.insert(p->projection.begin(), p->projection.end());
-      return make_scan(p->path, p->source_schema, p->batches, true, std::vector<std::string>(cols.begin(), cols.end()));
+      return make_scan(p->path, p->source_schema, p->batches, p->parquet, true, std::vector<std::string>(cols.begin(), cols.end()));
     }
     case LP_AGGREGATE: {
       for (auto &e : p->group_exprs) extract_columns(e, cols);
@@ -273,6 +275,14 @@ static std::unique_ptr<Plan> to_physical_plan(Context *ctx, const LogicalPlanPtr
   switch (p->kind) {
     case LP_SCAN: {
       out->kind = PK_SCAN;
+      if (p->parquet) {
+        // DataSource::scan(projection) (data_source.rs:48-71): the named columns, in file order
+        out->parquet = p->parquet;
+        if (p->has_projection) out->parquet_columns = parquet_project(*p->parquet, p->projection);
+        else
+          for (size_t i = 0; i < p->parquet->columns.size(); ++i) out->parquet_columns.push_back((int)i);
+        return out;
+      }
       for (auto &b : p->batches) {
         if (!p->has_projection) {
           out->batches.push_back(b);
@@ -414,6 +424,17 @@ qe_status qe_logical_expr_to_string(const qe_logical_expr *expr, char *buf, int6
 
 void qe_logical_expr_free(qe_logical_expr *expr) { delete expr; }
 
+qe_status qe_dataframe_parquet(qe_context *ctx, const char *path, qe_dataframe **out) {
+  return qe_guarded([&] {
+    if (!ctx || !path || !out) fail(QE_ERR_INVALID_ARGUMENT, "bad arguments");
+    *out = nullptr;
+    auto file = parquet_open(path);
+    Fields schema;  // infer_schema (data_source.rs:45-47)
+    for (auto &c : file->columns) schema.push_back(Field{c.name, c.type, c.optional});
+    *out = new qe_dataframe{qe_context_ref(ctx), make_scan(path, schema, {}, file, false, {})};
+  });
+}
+
 qe_status qe_dataframe_from_batches(qe_context *ctx, const char *label, const char *const *column_names, int32_t n_columns,
                                     qe_batch *const *batches, int32_t n_batches, qe_dataframe **out) {
   return qe_guarded([&] {
@@ -436,7 +457,7 @@ qe_status qe_dataframe_from_batches(qe_context *ctx, const char *label, const ch
         if (bt.cols[i].type != f.type) fail(QE_ERR_INVALID_ARGUMENT, "batches of one scan must share a schema");
       schema.push_back(f);  // Parquet columns are nullable in the reference's schema (tests/mod.rs:31)
     }
-    *out = new qe_dataframe{qe_context_ref(ctx), make_scan(label ? label : "memory", schema, bs, false, {})};
+    *out = new qe_dataframe{qe_context_ref(ctx), make_scan(label ? label : "memory", schema, bs, nullptr, false, {})};
   });
 }
 

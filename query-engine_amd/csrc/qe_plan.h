@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "qe_core.h"
+#include "qe_parquet.h"
 
 namespace qe {
 
@@ -16,7 +17,9 @@ struct Plan {
   PlanKind kind = PK_SCAN;
   Context *ctx = nullptr;
   std::unique_ptr<Plan> child;
-  std::vector<Batch> batches;        // scan
+  std::vector<Batch> batches;        // scan over memory
+  std::shared_ptr<ParquetFile> parquet;  // scan over a file: one batch per row group ...
+  std::vector<int> parquet_columns;      // ... of these columns
   std::vector<ExprPtr> exprs;        // projection
   ExprPtr pred;                      // selection
   std::vector<ExprPtr> group_exprs;  // aggregate

@@ -88,8 +88,12 @@ def _handles(exprs):
 class DataFrame:
     """struct DataFrame { plan } (dataframe.rs:29-84)."""
 
-    def __init__(self, ctx, names, batches, label="memory", steps=()):
+    def __init__(self, ctx, names, batches, label="memory", steps=(), path=None):
         self.ctx, self.names, self.batches, self.label, self.steps = ctx, list(names), list(batches), label, tuple(steps)
+        self.path = path  # a Parquet file scanned on the device instead of `batches`
+
+    def _with(self, step):
+        return DataFrame(self.ctx, self.names, self.batches, self.label, self.steps + (step,), self.path)
 
     # -- sources ------------------------------------------------------------
     @staticmethod
@@ -131,31 +135,33 @@ class DataFrame:
 
     @staticmethod
     def parquet(ctx, path):
-        """DataFrame::parquet (dataframe.rs:38-41).  The file is decoded on the host with pyarrow; the
-        reference's own Parquet reader (data_source.rs) is outside the device path."""
-        import pyarrow.parquet as pq
-        return DataFrame.from_arrow(ctx, pq.read_table(path), label=path)
+        """DataFrame::parquet (dataframe.rs:38-41): a scan of the file, one batch per row group, decoded
+        on the device (qe_dataframe_parquet).  Opening the file is deferred to the first use."""
+        return DataFrame(ctx, [], [], label=path, path=path)
 
     # -- builders (DataFrameTrait, dataframe.rs:44-69) ------------------------
     def project(self, exprs):
-        return DataFrame(self.ctx, self.names, self.batches, self.label, self.steps + (("project", list(exprs)),))
+        return self._with(("project", list(exprs)))
 
     def filter(self, expr):
-        return DataFrame(self.ctx, self.names, self.batches, self.label, self.steps + (("filter", expr),))
+        return self._with(("filter", expr))
 
     def aggregate(self, group_by, aggregate_expr):
-        return DataFrame(self.ctx, self.names, self.batches, self.label, self.steps + (("aggregate", list(group_by), list(aggregate_expr)),))
+        return self._with(("aggregate", list(group_by), list(aggregate_expr)))
 
     def optimize(self):
         """LogicalPlan::optimize: projection push-down (logical_plan/optimizer.rs)."""
-        return DataFrame(self.ctx, self.names, self.batches, self.label, self.steps + (("optimize",),))
+        return self._with(("optimize",))
 
     def _build(self):
         qe = _qe()
-        names = (C.c_char_p * max(1, len(self.names)))(*[n.encode() for n in self.names])
-        arr = (C.c_void_p * max(1, len(self.batches)))(*[b._h for b in self.batches])
         h = C.c_void_p()
-        qe._check(qe.lib.qe_dataframe_from_batches(self.ctx._h, self.label.encode(), names, len(self.names), arr, len(self.batches), C.byref(h)))
+        if self.path is not None:
+            qe._check(qe.lib.qe_dataframe_parquet(self.ctx._h, self.path.encode(), C.byref(h)))
+        else:
+            names = (C.c_char_p * max(1, len(self.names)))(*[n.encode() for n in self.names])
+            arr = (C.c_void_p * max(1, len(self.batches)))(*[b._h for b in self.batches])
+            qe._check(qe.lib.qe_dataframe_from_batches(self.ctx._h, self.label.encode(), names, len(self.names), arr, len(self.batches), C.byref(h)))
         for step in self.steps:
             out = C.c_void_p()
             try:

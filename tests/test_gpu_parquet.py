@@ -1,0 +1,275 @@
+"""Parquet scan leaf on the device (qe_plan_scan_parquet / qe_dataframe_parquet) against
+  * the reference's fixture userdata.parquet: its pinned schema (tests/mod.rs:31), the cells its tests
+    assert (tests/mod.rs:34-188), and every column bit for bit against the oracle's decode and the
+    golden dump;
+  * files written here with pyarrow (encodings, page versions, codecs, nulls, row groups) against the
+    oracle's decode and pyarrow's own — pyarrow is an independent Arrow implementation, not the reference.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from oracle import parquet_oracle as porc
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+USERDATA = os.path.join(HERE, "golden", "userdata.parquet")
+
+
+def column_equals_oracle(col, arr):
+    """Device column (host copy) vs oracle Array, bit for bit; null slots hold zeros / empty strings in both."""
+    n = len(arr)
+    assert len(col) == n
+    if arr.validity is None:
+        assert col.validity is None or bool(np.all(col.validity))
+    else:
+        assert col.validity is not None and np.array_equal(np.asarray(col.validity, dtype=bool), arr.validity)
+    if arr.type == orc.UTF8:
+        assert [bytes(v) for v in col.values] == arr.strings()
+    elif arr.type == orc.FLOAT64:
+        assert np.array_equal(np.asarray(col.values).view(np.uint64), arr.values.view(np.uint64))
+    else:
+        assert np.array_equal(np.asarray(col.values), arr.values)
+
+
+def scan_and_compare(qe, ctx, path, projection=None):
+    ref = porc.ParquetFile(path)
+    chunks = list(ref.scan(projection))
+    got = list(qe.ParquetScanExec(ctx, path, projection).execute())
+    assert len(got) == len(chunks) == len(ref.row_groups)
+    rows = 0
+    for b, ch in zip(got, chunks):
+        cols = b.columns()
+        assert len(cols) == len(ch.arrays)
+        for c, a in zip(cols, ch.arrays):
+            assert c.type == a.type
+            column_equals_oracle(c, a)
+        rows += b.num_rows
+    assert rows == ref.num_rows
+    return got
+
+
+# ----------------------------------------------------------------- the reference's fixture
+def test_userdata_every_column(qe, ctx):
+    got = scan_and_compare(qe, ctx, USERDATA)
+    g = np.load(os.path.join(HERE, "golden", "userdata.npz"))
+    cols = got[0].columns()
+    names = [f["name"] for f in qe.parquet_schema(USERDATA)["fields"]]
+    for name, c in zip(names, cols):
+        assert np.array_equal(np.asarray(c.validity, dtype=bool), g[name + ".valid"])
+        if c.type == qe.TYPE_UTF8:
+            offs = g[name + ".offsets"]
+            raw = g[name + ".bytes"].tobytes()
+            assert [bytes(v) for v in c.values] == [raw[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+        else:
+            assert np.array_equal(np.asarray(c.values), g[name + ".values"])
+
+
+def strings(col, n):
+    return [bytes(v).decode() for v in col.values[:n]]
+
+
+def test_reference_schema(qe, ctx):  # tests/mod.rs:28-32, the Debug string field by field
+    df = qe.DataFrame.parquet(ctx, USERDATA)
+    got = [(f["name"], f["data_type"], f["is_nullable"]) for f in df.schema()]
+    want = [("registration_dttm", "Timestamp(Nanosecond, None)"), ("id", "Int32"), ("first_name", "Utf8"), ("last_name", "Utf8"),
+            ("email", "Utf8"), ("gender", "Utf8"), ("ip_address", "Utf8"), ("cc", "Utf8"), ("country", "Utf8"), ("birthdate", "Utf8"),
+            ("salary", "Float64"), ("title", "Utf8"), ("comments", "Utf8")]
+    assert got == [(n, t, True) for n, t in want]
+
+
+def test_reference_scan(qe, ctx):  # tests/mod.rs:34-84
+    result = qe.DataFrame.parquet(ctx, USERDATA).execute()
+    cols = result[0].columns()
+    assert strings(cols[2], 2) == ["Amanda", "Albert"] and strings(cols[3], 2) == ["Jordan", "Freeman"]
+
+
+def test_reference_projection(qe, ctx):  # tests/mod.rs:86-136
+    P = qe.prelude
+    result = qe.DataFrame.parquet(ctx, USERDATA).project([P.col("email"), P.col("country")]).execute()
+    cols = result[0].columns()
+    assert len(cols) == 2
+    assert strings(cols[0], 2) == ["ajordan0@com.com", "afreeman1@is.gd"] and strings(cols[1], 2) == ["Indonesia", "Canada"]
+
+
+def test_reference_filter(qe, ctx):  # tests/mod.rs:138-188: every column compacted, order kept
+    P = qe.prelude
+    result = qe.DataFrame.parquet(ctx, USERDATA).filter(P.col("gender").eq(P.lit_string("Female"))).execute()
+    cols = result[0].columns()
+    assert len(cols) == 13 and result[0].num_rows == 482
+    assert strings(cols[2], 2) == ["Amanda", "Evelyn"] and strings(cols[3], 2) == ["Jordan", "Morgan"]
+    assert cols[0].type == qe.TYPE_TIMESTAMP_NS  # the timestamp column passes through the selection
+    ref = porc.ParquetFile(USERDATA)
+    ts = list(ref.scan(["registration_dttm", "gender"]))[0].arrays
+    keep = np.array([s == b"Female" for s in ts[1].strings()])
+    assert np.array_equal(np.asarray(cols[0].values), ts[0].values[keep])
+
+
+def test_reference_max_by_country(qe, ctx):  # tests/mod.rs:190-207 (its assertion cannot hold; the plan is what counts)
+    import json
+    P = qe.prelude
+    df = qe.DataFrame.parquet(ctx, USERDATA).aggregate([P.col("country")], [P.max(P.col("salary")), P.count(P.col("salary"))]).optimize()
+    assert "projection=country, salary" in df.logical_plan()
+    cols = df.execute()[0].columns()
+    exp = json.load(open(os.path.join(HERE, "golden", "userdata_expected.json")))["country_stats"]
+    got = {bytes(k).decode(): (m, c) for k, m, c in zip(cols[0].values, np.asarray(cols[1].values), np.asarray(cols[2].values))}
+    assert len(got) == len(exp) == 120
+    for country, st in exp.items():
+        m, c = got[country]
+        assert c == st["nn"]
+        if st["nn"]:
+            assert m == st["max"]
+
+
+def test_timestamp_only_passes_through(qe, ctx):
+    P = qe.prelude
+    with pytest.raises(qe.QeError) as e:
+        qe.DataFrame.parquet(ctx, USERDATA).filter(P.col("registration_dttm").eq(P.lit_int64(0))).execute()
+    assert e.value.name in ("PrimitiveTypeNotSuported", "PhysicalTypeNotSuported")
+
+
+# ----------------------------------------------------------------- files written here
+def sample_table(n, seed=1):
+    import pyarrow as pa
+    rng = np.random.default_rng(seed)
+    return pa.table({
+        "i": pa.array(rng.integers(-1000, 1000, n).astype(np.int32), mask=rng.random(n) < 0.1),
+        "l": pa.array(rng.integers(-10**12, 10**12, n)),
+        "d": pa.array(rng.standard_normal(n), mask=rng.random(n) < 0.3),
+        "b": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.2),
+        "s": pa.array([None if x % 7 == 0 else "k%d" % (x % 50) for x in range(n)]),
+        "u": pa.array(["row-%d" % x * (x % 3) for x in range(n)]),
+        "c": pa.array(np.repeat(rng.integers(0, 5, (n + 99) // 100), 100)[:n]),  # long runs -> RLE dictionary indices
+    })
+
+
+WRITER_OPTIONS = [
+    dict(compression="none"),
+    dict(compression="snappy"),
+    dict(compression="gzip", data_page_version="2.0"),
+    dict(compression="zstd", data_page_size=8192),
+    dict(compression="lz4", data_page_version="2.0", use_dictionary=False),
+    dict(compression="snappy", use_dictionary=False, data_page_version="2.0", row_group_size=1500, data_page_size=4096),
+    dict(compression="none", use_dictionary=False, row_group_size=1500, data_page_size=2048),
+    dict(compression="none", use_dictionary=["s", "c"], row_group_size=4000, data_page_size=1024, dictionary_pagesize_limit=256),
+]
+
+
+@pytest.mark.parametrize("options", WRITER_OPTIONS, ids=lambda o: "-".join(f"{k}={v}" for k, v in o.items())[:60])
+def test_written_files(qe, ctx, tmp_path, options):
+    import pyarrow.parquet as pq
+    tbl = sample_table(5000)
+    path = str(tmp_path / "t.parquet")
+    pq.write_table(tbl, path, **options)
+    if options["compression"] in ("zstd", "lz4"):  # codecs the oracle lacks: pyarrow is the only check
+        got = list(qe.ParquetScanExec(ctx, path).execute())
+    else:
+        got = scan_and_compare(qe, ctx, path)
+    for j, name in enumerate(tbl.column_names):
+        vals = []
+        for b in got:
+            vals += b.columns()[j].to_pylist()
+        assert vals == tbl.column(name).to_pylist(), name
+
+
+def test_required_columns_and_projection_order(qe, ctx, tmp_path):
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    n = 3000
+    rng = np.random.default_rng(3)
+    schema = pa.schema([pa.field("a", pa.int64(), nullable=False), pa.field("f", pa.float64(), nullable=False),
+                        pa.field("t", pa.string(), nullable=False), pa.field("g", pa.bool_(), nullable=False)])
+    tbl = pa.table([pa.array(rng.integers(0, 9, n)), pa.array(rng.random(n)), pa.array(["x" * (i % 5) for i in range(n)]),
+                    pa.array(rng.random(n) < 0.3)], schema=schema)
+    path = str(tmp_path / "req.parquet")
+    pq.write_table(tbl, path, compression="snappy", row_group_size=1000)
+    sch = qe.parquet_schema(path)
+    assert [f["is_nullable"] for f in sch["fields"]] == [False] * 4 and sch["row_groups"] == 3
+    got = scan_and_compare(qe, ctx, path)
+    assert all(c.validity is None for c in got[0].columns())
+    # the projection names columns; the scan keeps the file's order (data_source.rs:49-62)
+    got = scan_and_compare(qe, ctx, path, ["g", "a"])
+    assert [c.type for c in got[0].columns()] == [qe.TYPE_INT64, qe.TYPE_BOOLEAN]
+    assert list(qe.ParquetScanExec(ctx, path, []).execute())[0].num_columns == 0
+
+
+def test_plan_over_a_file(qe, ctx, tmp_path):
+    """Scan -> Selection -> Aggregate over a multi-row-group file equals the oracle over its decode."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    n = 200_000
+    rng = np.random.default_rng(5)
+    tbl = pa.table({"k": pa.array(rng.integers(0, 10, n)), "v": pa.array(rng.random(n), mask=rng.random(n) < 0.05),
+                    "c": pa.array(rng.random(n))})
+    path = str(tmp_path / "plan.parquet")
+    pq.write_table(tbl, path, compression="snappy", row_group_size=60_000)
+    pred = lambda m: m.GtExpression(m.ColumnExpression(2), m.LiteralFloatExpression(0.5))
+    groups = lambda m: [m.ColumnExpression(0)]
+    aggs = lambda m: [m.SumExpression(m.ColumnExpression(1)), m.CountExpression(m.ColumnExpression(1)), m.MinExpression(m.ColumnExpression(1))]
+    plan = qe.AggregateExec(qe.SelectionExec(qe.ParquetScanExec(ctx, path), pred(qe)), groups(qe), aggs(qe))
+    got = list(plan.execute())[0].columns()
+    chunks = list(porc.ParquetFile(path).scan())
+    want = list(orc.AggregateExec(orc.SelectionExec(orc.ScanExec(chunks), pred(orc)), groups(orc), aggs(orc)).execute())[0]
+    order_g, order_w = np.argsort(np.asarray(got[0].values)), np.argsort(want.arrays[0].values)
+    assert np.array_equal(np.asarray(got[0].values)[order_g], want.arrays[0].values[order_w])
+    assert np.allclose(np.asarray(got[1].values)[order_g], want.arrays[1].values[order_w], rtol=1e-12, atol=0)
+    assert np.array_equal(np.asarray(got[2].values)[order_g], want.arrays[2].values[order_w])
+    assert np.array_equal(np.asarray(got[3].values)[order_g], want.arrays[3].values[order_w])
+
+
+def test_many_pages(qe, ctx, tmp_path):
+    """A row group of 1.5 M rows in small pages: the page and run tables get long, strings cross pages."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    n = 1_500_000
+    rng = np.random.default_rng(9)
+    key = rng.integers(0, 1000, n)
+    tbl = pa.table({"x": pa.array(rng.random(n), mask=rng.random(n) < 0.01), "k": pa.array(key.astype(np.int32)),
+                    "name": pa.array(np.char.add("n", key.astype(str)))})
+    path = str(tmp_path / "big.parquet")
+    pq.write_table(tbl, path, compression="none", data_page_size=64 * 1024, row_group_size=n)
+    got = list(qe.ParquetScanExec(ctx, path).execute())
+    assert len(got) == 1 and got[0].num_rows == n
+    cols = got[0].columns()
+    x = tbl.column("x").combine_chunks()
+    assert np.array_equal(np.asarray(cols[0].validity, dtype=bool), np.asarray(x.is_valid()))
+    assert np.array_equal(np.asarray(cols[0].values).view(np.uint64), np.asarray(x.fill_null(0.0)).view(np.uint64))
+    assert np.array_equal(np.asarray(cols[1].values), key.astype(np.int32))
+    assert [bytes(v) for v in cols[2].values[:1000]] == [("n%d" % k).encode() for k in key[:1000]]
+    assert [bytes(v) for v in cols[2].values[-1000:]] == [("n%d" % k).encode() for k in key[-1000:]]
+
+
+# ----------------------------------------------------------------- errors
+def test_errors(qe, ctx, tmp_path):
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    with pytest.raises(qe.QeError) as e:  # ParquetDataSource::new -> Error::IoError (data_source.rs:39)
+        list(qe.ParquetScanExec(ctx, str(tmp_path / "missing.parquet")).execute())
+    assert e.value.name == "IoError"
+    bad = tmp_path / "bad.parquet"
+    bad.write_bytes(b"PAR1" + b"\x00" * 64 + b"PAR1")
+    with pytest.raises(qe.QeError) as e:  # read_metadata fails -> Error::ArrowError (data_source.rs:33)
+        list(qe.ParquetScanExec(ctx, str(bad)).execute())
+    assert e.value.name == "ArrowError"
+    # a column type the engine has no representation for: scanning it fails, leaving it out works
+    path = str(tmp_path / "f32.parquet")
+    pq.write_table(pa.table({"a": pa.array([1, 2, 3]), "f": pa.array(np.float32([1, 2, 3]))}), path)
+    with pytest.raises(qe.QeError) as e:
+        list(qe.ParquetScanExec(ctx, path).execute())
+    assert e.value.name == "PhysicalTypeNotSuported"
+    assert list(qe.ParquetScanExec(ctx, path, ["a"]).execute())[0].columns()[0].to_pylist() == [1, 2, 3]
+    # delta encodings are outside this reader
+    path = str(tmp_path / "delta.parquet")
+    pq.write_table(pa.table({"a": pa.array(np.arange(1000))}), path, use_dictionary=False, column_encoding={"a": "DELTA_BINARY_PACKED"})
+    with pytest.raises(qe.QeError) as e:
+        list(qe.ParquetScanExec(ctx, path).execute())
+    assert e.value.name == "ArrowError"
+    # truncated file
+    data = open(USERDATA, "rb").read()
+    cut = tmp_path / "cut.parquet"
+    cut.write_bytes(data[:50000] + data[-2000:])
+    with pytest.raises(qe.QeError):
+        list(qe.ParquetScanExec(ctx, str(cut)).execute())

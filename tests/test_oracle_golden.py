@@ -258,3 +258,43 @@ def test_literal_aggregate_matches_single_pass_and_quirks():
     a2 = list(orc.AggregateExec([orc.ScanExec(chunks)], [orc.ColumnExpression(0), orc.ColumnExpression(1)], aggs, literal=True).execute())[0]
     b2 = list(orc.AggregateExec([orc.ScanExec(chunks)], [orc.ColumnExpression(0), orc.ColumnExpression(1)], aggs).execute())[0]
     assert len(b2) == 36 and len(a2) == 21
+
+
+# ----------------------------------------------------------------- Parquet scan oracle
+def test_parquet_oracle_decodes_the_reference_fixture():
+    """oracle/parquet_oracle.py on the reference's userdata.parquet: the schema the reference pins
+    (tests/mod.rs:31), the cells its tests assert (tests/mod.rs:40-83), and every column against the
+    dump pyarrow made of the same file (tests/golden/userdata.npz)."""
+    import os
+    from oracle import parquet_oracle as porc
+    here = os.path.dirname(os.path.abspath(__file__))
+    f = porc.ParquetFile(os.path.join(here, "golden", "userdata.parquet"))
+    schema = f.schema()
+    assert schema[0] == ("registration_dttm", "Timestamp(Nanosecond, None)", True)
+    assert schema[1] == ("id", "Int32", True) and schema[10] == ("salary", "Float64", True)
+    assert all(t == "Utf8" and nullable for _, t, nullable in schema[2:10] + schema[11:])
+    chunks = list(f.scan())
+    assert len(chunks) == 1
+    arrays = chunks[0].arrays
+    assert arrays[2].strings()[:2] == [b"Amanda", b"Albert"] and arrays[3].strings()[:2] == [b"Jordan", b"Freeman"]
+    g = np.load(os.path.join(here, "golden", "userdata.npz"))
+    for (name, _, _), a in zip(schema, arrays):
+        assert np.array_equal(a.validity, g[name + ".valid"]), name
+        if a.type == orc.UTF8:
+            assert np.array_equal(a.values[0], g[name + ".offsets"]) and np.array_equal(a.values[1], g[name + ".bytes"]), name
+        else:
+            assert np.array_equal(a.values, g[name + ".values"]), name
+    # projection: named columns, file order (data_source.rs:49-62)
+    proj = list(f.scan(["salary", "id"]))[0].arrays
+    assert [a.type for a in proj] == [orc.INT32, orc.FLOAT64]
+
+
+def test_parquet_schema_through_the_abi(qe):
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    s = qe.parquet_schema(os.path.join(here, "golden", "userdata.parquet"))
+    assert s["rows"] == 1000 and s["row_groups"] == 1 and len(s["fields"]) == 13
+    assert s["fields"][0]["data_type"] == "Timestamp(Nanosecond, None)" and s["fields"][10]["data_type"] == "Float64"
+    with pytest.raises(qe.QeError) as e:
+        qe.parquet_schema(os.path.join(here, "golden", "missing.parquet"))
+    assert e.value.name == "IoError"
