@@ -350,7 +350,45 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
     entry("C4_groupby_zipf_1Mkeys_500M", r4, dt, prof, "qe_aggregate_static", BYTES_PER_ROW["c4"], len(b4),
           {"groups": out.num_rows, "kernels_ms_per_step": {kk: vv["ms"] / 2 for kk, vv in prof.items()},
            "note": "bound by LDS atomics and the partition pass, not by HBM: see kernels_ms_per_step"})
+    del zk, b4, out
+
+    # The headline plan read straight off a Parquet file (uncompressed, PLAIN Float64 + dictionary Int64 key; 16 M
+    # rows in row groups of 8 M): host reads the page cache into pinned memory, the GPU decodes.  Host-link bound.
+    try:
+        res["parquet_scan_headline_plan_16M"] = parquet_config(qe, ctx, torch, k, a, b, c, min(n, 16_000_000))
+    except ImportError as e:  # pyarrow writes the file
+        res["parquet_scan_headline_plan_16M"] = {"skipped": str(e)}
     return res
+
+
+def parquet_config(qe, ctx, torch, k, a, b, c, rows):
+    import tempfile
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    C = qe.ColumnExpression
+    tbl = pa.table({name: pa.array(t[:rows].cpu().numpy()) for name, t in (("k", k), ("a", a), ("b", b), ("c", c))})
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "headline.parquet")
+        pq.write_table(tbl, path, compression="none", use_dictionary=["k"], row_group_size=8_000_000)
+        size = os.path.getsize(path)
+
+        def plan():
+            sel = qe.SelectionExec([qe.ParquetScanExec(ctx, path)], qe.GtExpression(C(3), qe.LiteralFloatExpression(0.5)))
+            proj = qe.ProjectionExec([sel], [C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
+            return list(qe.AggregateExec([proj], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None)],
+                                         group_capacity_hint=64).execute())[0]
+        dt, prof, out = timed(ctx, torch, plan, 5, 2)
+        dt_scan, prof_scan, _ = timed(ctx, torch, lambda: list(qe.ParquetScanExec(ctx, path).execute()), 5, 1)
+        t0 = time.perf_counter()
+        pq.read_table(path)
+        dt_arrow = time.perf_counter() - t0
+    decode_ms = sum(v["ms"] for kk, v in prof_scan.items() if kk.startswith("qe_parquet")) / 5
+    return {"rows": rows, "file_bytes": size, "rows_per_s": rows / dt, "ms_per_step": dt * 1e3, "groups": out.num_rows,
+            "scan_only_ms": dt_scan * 1e3, "scan_only_file_GBps": size / dt_scan / 1e9, "scan_only_decoded_GBps": rows * 32 / dt_scan / 1e9,
+            "decode_kernels_ms_per_scan": decode_ms,
+            "pyarrow_read_table_ms": dt_arrow * 1e3,
+            "note": "end to end from the page cache; bound by the host link (pinned copy + PCIe), the decode kernels are a "
+                    "few percent of it; pyarrow.read_table on the host cores is an Arrow sibling, not the reference's reader"}
 
 
 def cpu_baseline(rows, seed):

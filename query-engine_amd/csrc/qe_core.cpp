@@ -86,6 +86,10 @@ Context::~Context() {
   }
   for (auto &kv : pool)
     for (void *q : kv.second) (void)hipFree(q);
+  for (Staging &s : staging) {
+    if (s.copied) (void)hipEventDestroy(s.copied);
+    if (s.ptr) (void)hipHostFree(s.ptr);
+  }
   if (filter_scratch) (void)hipFree(filter_scratch);
   if (counters) (void)hipFree(counters);
   if (host_counters) (void)hipHostFree(host_counters);

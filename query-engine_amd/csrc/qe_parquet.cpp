@@ -12,8 +12,13 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
+#include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <mutex>
+#include <thread>
 
 #include "qe_parquet_kernels.h"
 
@@ -364,15 +369,67 @@ int walk_runs(const uint8_t *image, uint32_t off, uint32_t len, int bit_width, i
 
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-void ensure_staging(ParquetFile &f, Context *ctx, size_t bytes) {
-  if (bytes <= f.staging_cap) return;
-  ctx->sync();
-  if (f.staging) QE_HIP(hipHostFree(f.staging));
-  f.staging = nullptr;
-  f.staging_cap = 0;
-  const size_t cap = std::max(bytes + bytes / 2, (size_t)1 << 20);
-  QE_HIP(hipHostMalloc(&f.staging, cap, hipHostMallocDefault));
-  f.staging_cap = cap;
+// Host threads for the two bulk jobs of a scan: copying the file's bytes out of the page cache and
+// decompressing pages.  QE_IO_THREADS overrides the default of 8.
+size_t io_threads() {
+  static const size_t n = [] {
+    const char *e = getenv("QE_IO_THREADS");
+    long v = e ? atol(e) : 0;
+    if (v <= 0) v = std::min<long>(8, std::max<long>(1, (long)std::thread::hardware_concurrency()));
+    return (size_t)std::min<long>(v, 64);
+  }();
+  return n;
+}
+
+template <typename F>
+void parallel_for(size_t n, F fn) {
+  const size_t t = std::min(n, io_threads());
+  if (t <= 1) {
+    for (size_t i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::atomic<size_t> next{0};
+  std::exception_ptr err;
+  std::mutex m;
+  auto work = [&] {
+    try {
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= n) break;
+        fn(i);
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> g(m);
+      if (!err) err = std::current_exception();
+      next.store(n);
+    }
+  };
+  std::vector<std::thread> threads;
+  for (size_t k = 0; k + 1 < t; ++k) threads.emplace_back(work);
+  work();
+  for (auto &th : threads) th.join();
+  if (err) std::rethrow_exception(err);
+}
+
+// The staging buffer to fill next, at least `bytes` large; waits until the copy that last read it is done.
+Context::Staging &take_staging(Context *ctx, size_t bytes) {
+  Context::Staging &s = ctx->staging[ctx->next_staging];
+  ctx->next_staging ^= 1;
+  ctx->bind();
+  if (s.pending) {
+    QE_HIP(hipEventSynchronize(s.copied));
+    s.pending = false;
+  }
+  if (bytes > s.cap) {
+    if (s.ptr) QE_HIP(hipHostFree(s.ptr));
+    s.ptr = nullptr;
+    s.cap = 0;
+    const size_t cap = std::max(bytes + bytes / 4, (size_t)1 << 20);
+    QE_HIP(hipHostMalloc(&s.ptr, cap, hipHostMallocDefault));
+    s.cap = cap;
+  }
+  if (!s.copied) QE_HIP(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+  return s;
 }
 
 void read_exact(const ParquetFile &f, int64_t off, uint8_t *dst, size_t n) {
@@ -383,6 +440,11 @@ void read_exact(const ParquetFile &f, int64_t off, uint8_t *dst, size_t n) {
     if (r <= 0) fail(QE_ERR_IO, "IO error: parquet: cannot read " + f.path + (r < 0 ? std::string(": ") + strerror(errno) : ": unexpected end of file"));
     done += (size_t)r;
   }
+}
+
+void read_parallel(const ParquetFile &f, int64_t off, uint8_t *dst, size_t n) {
+  const size_t slice = (size_t)4 << 20;
+  parallel_for((n + slice - 1) / slice, [&](size_t i) { read_exact(f, off + (int64_t)(i * slice), dst + i * slice, std::min(slice, n - i * slice)); });
 }
 
 struct PageRec {
@@ -397,18 +459,23 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
   if (n_rows >= (int64_t)1 << 31) bad_file("row groups of 2^31 rows or more are not supported");
 
   // ---- raw bytes and page headers
-  std::vector<uint8_t> raw_vec;
-  uint8_t *raw;
+  // Sizes of the descriptor tables are only known after the pages have been walked; the worst
+  // case (a run header every other byte) cannot exceed a small multiple of the chunk itself, and
+  // the common case is tiny, so the staging buffer gets a fixed allowance and grows if it must.
   const size_t raw_len = (size_t)cm.size;
+  const size_t table_room = ((size_t)1 << 16) + raw_len / 8;
+  std::unique_ptr<uint8_t[]> raw_heap;
+  uint8_t *raw;
+  Context::Staging *stage = nullptr;
   if (cm.codec == CODEC_NONE) {
-    // the image is the chunk as it lies in the file: read it straight into the pinned buffer
-    ensure_staging(f, ctx, align16(raw_len + 16) + ((size_t)1 << 16));
-    raw = (uint8_t *)f.staging;
+    // the image is the chunk as it lies in the file: read it straight into pinned memory
+    stage = &take_staging(ctx, align16(raw_len + 16) + table_room);
+    raw = (uint8_t *)stage->ptr;
   } else {
-    raw_vec.resize(raw_len + 16);
-    raw = raw_vec.data();
+    raw_heap.reset(new uint8_t[raw_len + 16]);
+    raw = raw_heap.get();
   }
-  read_exact(f, cm.start, raw, raw_len);
+  read_parallel(f, cm.start, raw, raw_len);
   std::vector<PageRec> recs;
   size_t image_need = 0;
   {
@@ -430,7 +497,7 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
     if (seen != n_rows) bad_file("column `" + col.name + "`: pages hold " + std::to_string(seen) + " values, the row group " + std::to_string(n_rows) + " rows");
   }
 
-  // ---- image: page bodies, decompressed where needed
+  // ---- image: page bodies, decompressed where needed (pages are independent: one task each)
   uint8_t *image;
   size_t image_len;
   std::vector<size_t> body_at(recs.size());  // image offset of each page's (uncompressed) body
@@ -442,25 +509,29 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
       body_at[i] = recs[i].body;
     }
   } else {
-    ensure_staging(f, ctx, image_need + ((size_t)1 << 16));
-    image = (uint8_t *)f.staging;
+    stage = &take_staging(ctx, image_need + ((size_t)1 << 16) + image_need / 8);
+    image = (uint8_t *)stage->ptr;
     size_t at = 0;
     for (size_t i = 0; i < recs.size(); ++i) {
+      body_at[i] = at;
+      at += align16((size_t)recs[i].h.uncompressed + 16);
+    }
+    image_len = at;
+    parallel_for(recs.size(), [&](size_t i) {
       const PageHeader &h = recs[i].h;
       const uint8_t *src = raw + recs[i].body;
-      body_at[i] = at;
+      uint8_t *dst = image + body_at[i];
       if (h.type == PAGE_DATA_V2) {
         // levels are stored uncompressed in front of the (optionally compressed) values
         const size_t lv = (size_t)h.def_len + (size_t)h.rep_len;
         if (lv > (size_t)h.compressed || lv > (size_t)h.uncompressed) bad_file("corrupt v2 page");
-        memcpy(image + at, src, lv);
-        decompress(h.v2_compressed ? cm.codec : CODEC_NONE, src + lv, (size_t)h.compressed - lv, image + at + lv, (size_t)h.uncompressed - lv);
+        memcpy(dst, src, lv);
+        decompress(h.v2_compressed ? cm.codec : CODEC_NONE, src + lv, (size_t)h.compressed - lv, dst + lv, (size_t)h.uncompressed - lv);
       } else {
-        decompress(cm.codec, src, (size_t)h.compressed, image + at, (size_t)h.uncompressed);
+        decompress(cm.codec, src, (size_t)h.compressed, dst, (size_t)h.uncompressed);
       }
-      at += align16((size_t)h.uncompressed + 16);
-    }
-    image_len = at;
+      memset(dst + h.uncompressed, 0, align16((size_t)h.uncompressed + 16) - (size_t)h.uncompressed);
+    });
   }
   if (image_len >= ((size_t)1 << 32) - 64) bad_file("column chunks of 4 GiB or more are not supported");
 
@@ -560,14 +631,15 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
   const size_t walks_at = at;
   at = align16(at + walks.size() * sizeof(PqWalk));
   const size_t total = at + 16;
-  if (total > f.staging_cap) {
+  if (total > stage->cap) {
     // tables did not fit behind the image: move to a larger pinned buffer
     std::vector<uint8_t> keep(image, image + image_len);
-    ensure_staging(f, ctx, total);
-    image = (uint8_t *)f.staging;
+    ctx->next_staging = (int)(stage - ctx->staging);
+    stage = &take_staging(ctx, total);
+    image = (uint8_t *)stage->ptr;
     memcpy(image, keep.data(), image_len);
   }
-  uint8_t *st = (uint8_t *)f.staging;
+  uint8_t *st = (uint8_t *)stage->ptr;
   memset(st + image_len, 0, pages_at - image_len);
   if (!pages.empty()) memcpy(st + pages_at, pages.data(), pages.size() * sizeof(PqPage));
   if (!runs.empty()) memcpy(st + runs_at, runs.data(), runs.size() * sizeof(PqRun));
@@ -577,14 +649,11 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
   ctx->bind();
   BufferPtr dev = device_buffer(ctx, total);
   QE_HIP(hipMemcpyAsync(dev->ptr, st, total, hipMemcpyHostToDevice, ctx->stream));
+  QE_HIP(hipEventRecord(stage->copied, ctx->stream));
+  stage->pending = true;
   const uint8_t *d = (const uint8_t *)dev->ptr;
 
-  if (!ctx->counters) {
-    QE_HIP(hipMalloc((void **)&ctx->counters, 64 * sizeof(unsigned long long)));
-    QE_HIP(hipHostMalloc((void **)&ctx->host_counters, 64 * sizeof(unsigned long long), hipHostMallocDefault));
-  }
-  unsigned long long *err = ctx->counters + 32;
-  QE_HIP(hipMemsetAsync(err, 0, sizeof(unsigned long long), ctx->stream));
+  unsigned long long *err = ctx->counters + 32;  // cleared and checked once per row group
 
   Column out;
   out.type = col.type;
@@ -621,7 +690,6 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
       QE_HIP(launch_exclusive_scan_i32((int32_t *)word_rank->ptr, (int64_t)n_words + 1, (int32_t *)tmp->ptr, ctx->stream));
       ck.validity = (const uint64_t *)out.validity->ptr;
       ck.word_rank = (const int32_t *)word_rank->ptr;
-      ctx->sync();  // `tmp` goes back to the pool
     }
   }
 
@@ -662,9 +730,8 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
     QE_HIP(launch_pq_utf8_copy(d, (const uint32_t *)row_src->ptr, offs, (int32_t)n_rows, (uint8_t *)out.values->ptr, ctx->stream));
     ctx->prof_end();
   }
-  QE_HIP(hipMemcpyAsync(ctx->host_counters + 9, err, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-  ctx->sync();  // the staging buffer and the temporaries are free again
-  if (ctx->host_counters[9]) bad_file("column `" + col.name + "`: page contents contradict their headers");
+  // Temporaries go back to the pool here while the stream may still use them: the pool only hands
+  // blocks to work queued later on the same stream.
   return out;
 }
 
@@ -672,7 +739,6 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
 
 ParquetFile::~ParquetFile() {
   if (fd >= 0) close(fd);
-  if (staging) (void)hipHostFree(staging);
 }
 
 std::shared_ptr<ParquetFile> parquet_open(const std::string &path) {
@@ -788,10 +854,20 @@ Batch parquet_read_row_group(Context *ctx, ParquetFile &file, int row_group, con
   Batch b;
   b.ctx = ctx;
   b.rows = rg.num_rows;
+  ctx->bind();
+  if (!ctx->counters) {
+    QE_HIP(hipMalloc((void **)&ctx->counters, 64 * sizeof(unsigned long long)));
+    QE_HIP(hipHostMalloc((void **)&ctx->host_counters, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+  }
+  unsigned long long *err = ctx->counters + 32;
+  QE_HIP(hipMemsetAsync(err, 0, sizeof(unsigned long long), ctx->stream));
   for (int c : columns) {
     if (c < 0 || c >= (int)file.columns.size()) fail(QE_ERR_EXCEEDING_BOUNDS, "column index out of range");
     b.cols.push_back(decode_chunk(ctx, file, file.columns[c], rg.chunks[c], rg.num_rows));
   }
+  QE_HIP(hipMemcpyAsync(ctx->host_counters + 9, err, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  ctx->sync();
+  if (ctx->host_counters[9]) bad_file("row group " + std::to_string(row_group) + ": page contents contradict their headers");
   return b;
 }
 

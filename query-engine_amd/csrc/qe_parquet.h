@@ -37,9 +37,6 @@ struct ParquetFile {
   int64_t num_rows = 0;
   std::vector<ParquetColumn> columns;
   std::vector<ParquetRowGroup> row_groups;
-  // pinned staging for the host -> device copy of one column chunk
-  void *staging = nullptr;
-  size_t staging_cap = 0;
   ~ParquetFile();
 };
 
