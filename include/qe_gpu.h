@@ -122,6 +122,7 @@ typedef struct qe_expr qe_expr;
 typedef struct qe_agg_expr qe_agg_expr;
 typedef struct qe_plan qe_plan;
 typedef struct qe_iter qe_iter;
+typedef struct qe_agg_state qe_agg_state;
 
 /* One Arrow array, described by raw buffers.  Buffer order follows the Arrow
  * C data interface (validity, offsets, values). */
@@ -213,6 +214,25 @@ void qe_expr_free(qe_expr *expr);
  * (COUNT(*)). */
 qe_status qe_agg_expr_new(int32_t kind, qe_expr *input, qe_agg_expr **out);
 void qe_agg_expr_free(qe_agg_expr *agg);
+
+/* Accumulator protocol (physical_expressions.rs:351-362: create_accumulator,
+ * Accumulator::accumulate(&mut self, batch values, mask), final_value(self)) for
+ * callers that drive the batches themselves instead of handing over a plan.
+ * The state is the device group table, not one scalar per group and
+ * aggregate: qe_agg_update folds one device-resident batch in (one kernel
+ * launch, no synchronisation), qe_agg_finalize assembles the output batch the
+ * way AggregateExec does (physical_plan/mod.rs:375-488); it may be called more
+ * than once (running results).  Expression column indices refer to the
+ * batches' columns.  qe_agg_state_new consumes the expressions.  The batches'
+ * buffers stay borrowed until the state is freed: should the group table
+ * outgrow `group_capacity_hint`, finalize folds them in again into a larger
+ * one.  `mode` as for qe_plan_aggregate. */
+qe_status qe_agg_state_new(qe_context *ctx, qe_expr *const *group_exprs, int32_t n_group_exprs,
+                           qe_agg_expr *const *agg_exprs, int32_t n_agg_exprs, int32_t mode,
+                           int64_t group_capacity_hint, qe_agg_state **out);
+qe_status qe_agg_update(qe_agg_state *state, const qe_batch *batch);
+qe_status qe_agg_finalize(qe_agg_state *state, qe_batch **out);
+void qe_agg_state_free(qe_agg_state *state);
 
 /* ------------------------------------------------------------------ plans */
 /* In-memory scan leaf: stands where ScanExec::new(DataSource, projection,

@@ -81,6 +81,11 @@ ABI = {
     "qe_expr_free": (None, [C.c_void_p]),
     "qe_agg_expr_new": (C.c_int32, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "qe_agg_expr_free": (None, [C.c_void_p]),
+    "qe_agg_state_new": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int64,
+                                     C.POINTER(C.c_void_p)]),
+    "qe_agg_update": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "qe_agg_finalize": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "qe_agg_state_free": (None, [C.c_void_p]),
     "qe_plan_scan_memory": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]),
     "qe_plan_scan_parquet": (C.c_int32, [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_void_p)]),
     "qe_parquet_schema": (C.c_int32, [C.c_char_p, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
@@ -780,6 +785,50 @@ class AggregateExec(PhysicalPlan):
         h = C.c_void_p()
         _check(lib.qe_plan_aggregate(child, garr, len(gs), aarr, len(ags), self.mode, self.group_capacity_hint, C.byref(h)))
         return h
+
+
+class AggregationState:
+    """The Accumulator protocol (physical_expressions.rs:351-362) over the device group table:
+    `accumulate(batch)` folds one device-resident batch in, `final_value()` returns the output Batch."""
+
+    def __init__(self, ctx, group_exprs, agg_exprs, mode=AGG_MODE_SINGLE, group_capacity_hint=0):
+        self.ctx = ctx
+        self._batches = []  # the state borrows their buffers until it is freed
+        gs = _build_list(group_exprs)
+        ags = []
+        try:
+            for a in agg_exprs:
+                ags.append(a._build())
+        except Exception:
+            for g in gs:
+                lib.qe_expr_free(g)
+            for a in ags:
+                lib.qe_agg_expr_free(a)
+            raise
+        garr = (C.c_void_p * max(1, len(gs)))(*gs)
+        aarr = (C.c_void_p * max(1, len(ags)))(*ags)
+        self._h = C.c_void_p()
+        _check(lib.qe_agg_state_new(ctx._h, garr, len(gs), aarr, len(ags), mode, group_capacity_hint, C.byref(self._h)))
+
+    def accumulate(self, batch):
+        _check(lib.qe_agg_update(self._h, batch._h))
+        self._batches.append(batch)
+
+    def final_value(self):
+        b = C.c_void_p()
+        _check(lib.qe_agg_finalize(self._h, C.byref(b)))
+        return Batch(self.ctx, b)
+
+    def close(self):
+        if self._h:
+            lib.qe_agg_state_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def partial_layout(n_group_exprs, agg_exprs):

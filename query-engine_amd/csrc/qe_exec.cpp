@@ -747,6 +747,150 @@ static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &
   // the buffers go back to the pool on return: any later use is ordered behind these kernels on the stream
 }
 
+// Aggregation state fed one batch at a time: the device group table and what is needed to turn it
+// into the output batch.  AggregateExec::execute's loop body (physical_plan/mod.rs:298-374) is
+// `update`, its output assembly (:375-488) is `finish`.
+struct AggState {
+  Context *ctx = nullptr;
+  std::vector<ExprPtr> groups;  // over the columns `outputs` describes (or the batch's own, when empty)
+  std::vector<AggExpr> aggs;
+  int mode = QE_AGG_MODE_SINGLE;
+  int64_t cap_hint = 0;
+
+  uint64_t cap = 0;
+  bool have_table = false;
+  AggSpec spec;
+  AggTable table{};
+  BufferPtr table_buf;
+  std::vector<Utf8KeySource> key_sources;
+  int64_t row_base = 0;
+
+  // Fresh table for about `hint` groups.
+  void start(int64_t hint) {
+    cap = 1024;
+    while (cap < (uint64_t)hint * 2) cap <<= 1;
+    if (cap > (1ull << 30)) fail(QE_ERR_AGG_CAPACITY, "group table would exceed 2^30 slots");
+    have_table = false;
+    spec = AggSpec();
+    table = AggTable{};
+    table_buf.reset();
+    key_sources.clear();
+    row_base = 0;
+  }
+
+  // Folds one batch in.  `outputs` (may be empty = the batch's columns) are the expressions the
+  // group / aggregate expressions' column indices refer to; `pred` selects rows.
+  void update(const Batch &in, const std::vector<ExprPtr> &outputs, const ExprPtr &pred) {
+    ctx->bind();
+    ensure_counters(ctx);
+    std::vector<ExprPtr> src_outs = outputs;
+    if (src_outs.empty())
+      for (size_t i = 0; i < in.cols.size(); ++i) src_outs.push_back(make_column((int)i));
+    std::vector<ExprPtr> g2;
+    std::vector<AggExpr> a2;
+    std::vector<ExprPtr> a2_second;
+    for (auto &g : groups) g2.push_back(expr_substitute(g, src_outs));
+    for (auto &a : aggs) {
+      AggExpr x;
+      x.kind = a.kind;
+      x.input = a.input ? expr_substitute(a.input, src_outs) : nullptr;
+      a2.push_back(x);
+      ExprPtr second;
+      if (mode == QE_AGG_MODE_FINAL && a.kind == QE_AGG_AVG && a.input && a.input->kind == EK_COLUMN)
+        second = expr_substitute(make_column(a.input->index + 1), src_outs);
+      a2_second.push_back(second);
+    }
+    Schema schema = schema_of(in);
+    AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode, row_base);
+    if (bspec.utf8_key_col >= 0) key_sources.push_back(Utf8KeySource{in.cols[bspec.utf8_key_col], row_base});
+    row_base += in.rows;
+    if (!have_table) {
+      spec = bspec;
+      int na = (int)spec.accs.size();
+      table.cap = cap;
+      table.stride = (cap + 1 + 63) & ~63ull;
+      size_t words = table.stride * (2 + 2 * (size_t)na) + 8;
+      table_buf = device_buffer(ctx, words * 8);
+      unsigned long long *base = (unsigned long long *)table_buf->ptr;
+      table.keys = base;
+      table.rowcnt = base + table.stride;
+      table.acc = base + 2 * table.stride;
+      table.nn = table.acc + (size_t)na * table.stride;
+      table.ctrl = table.nn + (size_t)na * table.stride;
+      std::vector<VmAcc> va;
+      for (auto &d : spec.accs) va.push_back(d.acc);
+      ctx->prof_begin("qe_table_init_kernel");
+      QE_HIP(launch_table_init(table, va.data(), na, ctx->stream));
+      ctx->prof_end();
+      have_table = true;
+    } else {
+      bool same = bspec.accs.size() == spec.accs.size() && bspec.keys.size() == spec.keys.size();
+      for (size_t i = 0; same && i < spec.accs.size(); ++i)
+        same = bspec.accs[i].acc.op == spec.accs[i].acc.op && bspec.accs[i].acc.in_type == spec.accs[i].acc.in_type;
+      for (size_t i = 0; same && i < spec.keys.size(); ++i) same = bspec.keys[i].type == spec.keys[i].type;
+      if (!same) fail(QE_ERR_INVALID_ARGUMENT, "batches of one scan must share a schema");
+      // a later batch may be nullable where the first was not: keep the stricter tracking
+      for (size_t i = 0; i < spec.accs.size(); ++i)
+        if (bspec.accs[i].acc.track_nn && !spec.accs[i].acc.track_nn)
+          fail(QE_ERR_INVALID_ARGUMENT, "batches of one scan must share nullability");
+    }
+    if (in.rows == 0) return;
+    Compiler comp(ctx, &in);
+    AggArgs args{};
+    lower_aggregate(comp, schema, pred ? expr_normalize(pred, ctx->flags) : nullptr, bspec, spec, args);
+    args.table = table;
+    args.n_rows = in.rows;
+    args.lds_cap = aggregate_lds_slots(args.n_accs, ctx->dev, cap_hint);
+    args.lds_limit = args.lds_cap - args.lds_cap / 4;
+    SpillPlan sp = plan_spill(ctx, bspec, args, cap_hint);
+    const char *kname = "qe_aggregate_kernel";
+    ctx->prof_begin(kname);
+    QE_HIP(launch_aggregate(args, ctx->dev, ctx->stream, &kname));
+    ctx->prof_end(kname);
+    if (sp.on) aggregate_spilled(ctx, sp, args, cap_hint);
+    if (!comp.keepalive.empty()) ctx->sync();
+  }
+
+  // The output batch.  False when the table overflowed: the caller starts over with a larger one.
+  bool finish(Batch &result) {
+    ctx->bind();
+    // empty input: `iter.next().ok_or(Error::EmptyHashmapForAggregate)` (physical_plan/mod.rs:377)
+    if (!have_table) fail(QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE, "The hashmap for aggregation is empty.");
+    QE_HIP(hipMemcpyAsync(ctx->host_counters + 16, table.ctrl, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    unsigned long long n_groups = ctx->host_counters[16], overflow = ctx->host_counters[17];
+    if (overflow) return false;
+    if (n_groups == 0) fail(QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE, "The hashmap for aggregation is empty.");
+    // output assembly (physical_plan/mod.rs:375-488): key columns, then one column per aggregate
+    FinalizeArgs fa{};
+    fa.table = table;
+    fa.n_outs = (int)spec.outs.size();
+    result = Batch();
+    result.ctx = ctx;
+    result.rows = (int64_t)n_groups;
+    for (size_t i = 0; i < spec.outs.size(); ++i) {
+      FinOut f = spec.outs[i];
+      Column c = make_fixed_column(ctx, f.type, (int64_t)n_groups, f.null_mode != NULL_NEVER, false);
+      finish_fixed_column(c, (int64_t)n_groups);
+      f.values = c.values->ptr;
+      f.validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
+      fa.outs[i] = f;
+      result.cols.push_back(c);
+    }
+    QE_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
+    fa.out_count = ctx->counters;
+    ctx->prof_begin("qe_finalize_kernel");
+    QE_HIP(launch_finalize(fa, ctx->stream));
+    ctx->prof_end();
+    if (spec.utf8_key_out >= 0) {
+      Column &ids = result.cols[spec.utf8_key_out];
+      result.cols[spec.utf8_key_out] = utf8_gather_rows(ctx, key_sources, (const int64_t *)ids.values->ptr, (int64_t)n_groups);
+    }
+    ctx->sync();
+    return true;
+  }
+};
+
 struct AggIter : Iter {
   Context *ctx;
   Stream s;
@@ -758,127 +902,23 @@ struct AggIter : Iter {
   Batch result;
 
   void compute() {
-    ctx->bind();
-    ensure_counters(ctx);
+    AggState st;
+    st.ctx = ctx;
+    st.groups = groups;
+    st.aggs = aggs;
+    st.mode = mode;
+    st.cap_hint = cap_hint;
     int64_t hint = cap_hint > 0 ? cap_hint : 32768;
     for (int attempt = 0; attempt < 6; ++attempt) {
-      uint64_t cap = 1024;
-      while (cap < (uint64_t)hint * 2) cap <<= 1;
-      if (cap > (1ull << 30)) fail(QE_ERR_AGG_CAPACITY, "group table would exceed 2^30 slots");
+      st.start(hint);
       s.src->reset();
-      bool have_table = false;
-      AggSpec spec;
-      AggTable table{};
-      BufferPtr table_buf;
-      std::vector<int> key_types, acc_types;
-      std::vector<Utf8KeySource> key_sources;
-      int64_t row_base = 0;
       Batch in;
-      while (s.src->next(in)) {
-        int ncols = (int)in.cols.size();
-        std::vector<ExprPtr> src_outs = stream_outputs(s, ncols);
-        std::vector<ExprPtr> g2;
-        std::vector<AggExpr> a2;
-        std::vector<ExprPtr> a2_second;
-        for (auto &g : groups) g2.push_back(expr_substitute(g, src_outs));
-        for (auto &a : aggs) {
-          AggExpr x;
-          x.kind = a.kind;
-          x.input = a.input ? expr_substitute(a.input, src_outs) : nullptr;
-          a2.push_back(x);
-          ExprPtr second;
-          if (mode == QE_AGG_MODE_FINAL && a.kind == QE_AGG_AVG && a.input && a.input->kind == EK_COLUMN)
-            second = expr_substitute(make_column(a.input->index + 1), src_outs);
-          a2_second.push_back(second);
-        }
-        Schema schema = schema_of(in);
-        AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode, row_base);
-        if (bspec.utf8_key_col >= 0) key_sources.push_back(Utf8KeySource{in.cols[bspec.utf8_key_col], row_base});
-        row_base += in.rows;
-        if (!have_table) {
-          spec = bspec;
-          int na = (int)spec.accs.size();
-          table.cap = cap;
-          table.stride = (cap + 1 + 63) & ~63ull;
-          size_t words = table.stride * (2 + 2 * (size_t)na) + 8;
-          table_buf = device_buffer(ctx, words * 8);
-          unsigned long long *base = (unsigned long long *)table_buf->ptr;
-          table.keys = base;
-          table.rowcnt = base + table.stride;
-          table.acc = base + 2 * table.stride;
-          table.nn = table.acc + (size_t)na * table.stride;
-          table.ctrl = table.nn + (size_t)na * table.stride;
-          std::vector<VmAcc> va;
-          for (auto &d : spec.accs) va.push_back(d.acc);
-          ctx->prof_begin("qe_table_init_kernel");
-          QE_HIP(launch_table_init(table, va.data(), na, ctx->stream));
-          ctx->prof_end();
-          have_table = true;
-        } else {
-          bool same = bspec.accs.size() == spec.accs.size() && bspec.keys.size() == spec.keys.size();
-          for (size_t i = 0; same && i < spec.accs.size(); ++i)
-            same = bspec.accs[i].acc.op == spec.accs[i].acc.op && bspec.accs[i].acc.in_type == spec.accs[i].acc.in_type;
-          for (size_t i = 0; same && i < spec.keys.size(); ++i) same = bspec.keys[i].type == spec.keys[i].type;
-          if (!same) fail(QE_ERR_INVALID_ARGUMENT, "batches of one scan must share a schema");
-          // a later batch may be nullable where the first was not: keep the stricter tracking
-          for (size_t i = 0; i < spec.accs.size(); ++i)
-            if (bspec.accs[i].acc.track_nn && !spec.accs[i].acc.track_nn)
-              fail(QE_ERR_INVALID_ARGUMENT, "batches of one scan must share nullability");
-        }
-        if (in.rows == 0) continue;
-        Compiler comp(ctx, &in);
-        AggArgs args{};
-        lower_aggregate(comp, schema, s.pred ? expr_normalize(s.pred, ctx->flags) : nullptr, bspec, spec, args);
-        args.table = table;
-        args.n_rows = in.rows;
-        args.lds_cap = aggregate_lds_slots(args.n_accs, ctx->dev, cap_hint);
-        args.lds_limit = args.lds_cap - args.lds_cap / 4;
-        SpillPlan sp = plan_spill(ctx, bspec, args, cap_hint);
-        const char *kname = "qe_aggregate_kernel";
-        ctx->prof_begin(kname);
-        QE_HIP(launch_aggregate(args, ctx->dev, ctx->stream, &kname));
-        ctx->prof_end(kname);
-        if (sp.on) aggregate_spilled(ctx, sp, args, cap_hint);
-        if (!comp.keepalive.empty()) ctx->sync();
+      while (s.src->next(in)) st.update(in, stream_outputs(s, (int)in.cols.size()), s.pred);
+      if (st.finish(result)) {
+        done = true;
+        return;
       }
-      // empty input: `iter.next().ok_or(Error::EmptyHashmapForAggregate)` (physical_plan/mod.rs:377)
-      if (!have_table) fail(QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE, "The hashmap for aggregation is empty.");
-      QE_HIP(hipMemcpyAsync(ctx->host_counters + 16, table.ctrl, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-      ctx->sync();
-      unsigned long long n_groups = ctx->host_counters[16], overflow = ctx->host_counters[17];
-      if (overflow) {
-        hint = (int64_t)cap * 4;  // grow and run the aggregation again
-        continue;
-      }
-      if (n_groups == 0) fail(QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE, "The hashmap for aggregation is empty.");
-      // output assembly (physical_plan/mod.rs:375-488): key columns, then one column per aggregate
-      FinalizeArgs fa{};
-      fa.table = table;
-      fa.n_outs = (int)spec.outs.size();
-      result = Batch();
-      result.ctx = ctx;
-      result.rows = (int64_t)n_groups;
-      for (size_t i = 0; i < spec.outs.size(); ++i) {
-        FinOut f = spec.outs[i];
-        Column c = make_fixed_column(ctx, f.type, (int64_t)n_groups, f.null_mode != NULL_NEVER, false);
-        finish_fixed_column(c, (int64_t)n_groups);
-        f.values = c.values->ptr;
-        f.validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
-        fa.outs[i] = f;
-        result.cols.push_back(c);
-      }
-      QE_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
-      fa.out_count = ctx->counters;
-      ctx->prof_begin("qe_finalize_kernel");
-      QE_HIP(launch_finalize(fa, ctx->stream));
-      ctx->prof_end();
-      if (spec.utf8_key_out >= 0) {
-        Column &ids = result.cols[spec.utf8_key_out];
-        result.cols[spec.utf8_key_out] = utf8_gather_rows(ctx, key_sources, (const int64_t *)ids.values->ptr, (int64_t)n_groups);
-      }
-      ctx->sync();
-      done = true;
-      return;
+      hint = (int64_t)st.cap * 4;  // grow and run the aggregation again
     }
     fail(QE_ERR_AGG_CAPACITY, "group table still full after growing");
   }
@@ -1639,6 +1679,76 @@ qe_status qe_plan_aggregate(qe_plan *child, qe_expr *const *group_exprs, int32_t
     *out = new qe_plan{std::move(p)};
   });
 }
+
+// ------------------------------------------------------ streaming aggregation
+struct qe_agg_state {
+  AggState st;
+  std::vector<Batch> history;  // what has been folded in, should the table have to grow
+  int64_t hint = 0;
+  bool started = false;
+};
+
+qe_status qe_agg_state_new(qe_context *ctx, qe_expr *const *group_exprs, int32_t n_group_exprs, qe_agg_expr *const *agg_exprs,
+                           int32_t n_agg_exprs, int32_t mode, int64_t group_capacity_hint, qe_agg_state **out) {
+  return guarded([&] {
+    QE_REQUIRE(ctx && out && n_group_exprs >= 0 && n_agg_exprs >= 0 && (group_exprs || !n_group_exprs) && (agg_exprs || !n_agg_exprs), "bad arguments");
+    QE_REQUIRE(mode >= QE_AGG_MODE_SINGLE && mode <= QE_AGG_MODE_FINAL, "bad aggregate mode");
+    *out = nullptr;
+    auto s = std::make_unique<qe_agg_state>();
+    s->st.ctx = &ctx->c;
+    s->st.mode = mode;
+    s->st.cap_hint = group_capacity_hint;
+    s->hint = group_capacity_hint > 0 ? group_capacity_hint : 32768;
+    for (int i = 0; i < n_group_exprs; ++i) {
+      QE_REQUIRE(group_exprs[i], "group expr is null");
+      s->st.groups.push_back(group_exprs[i]->e);
+      delete group_exprs[i];
+    }
+    for (int i = 0; i < n_agg_exprs; ++i) {
+      QE_REQUIRE(agg_exprs[i], "aggregate expr is null");
+      s->st.aggs.push_back(agg_exprs[i]->a);
+      delete agg_exprs[i];
+    }
+    *out = s.release();
+  });
+}
+
+qe_status qe_agg_update(qe_agg_state *state, const qe_batch *batch) {
+  return guarded([&] {
+    QE_REQUIRE(state && batch, "bad arguments");
+    for (auto &c : batch->b.cols)
+      if (c.space != QE_MEM_DEVICE) fail(QE_ERR_INVALID_ARGUMENT, "batches must be device resident (qe_batch_to_device)");
+    if (!state->started) {
+      state->st.start(state->hint);
+      state->started = true;
+    }
+    state->st.update(batch->b, {}, nullptr);
+    state->history.push_back(batch->b);
+  });
+}
+
+qe_status qe_agg_finalize(qe_agg_state *state, qe_batch **out) {
+  return guarded([&] {
+    QE_REQUIRE(state && out, "bad arguments");
+    *out = nullptr;
+    if (!state->started) fail(QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE, "The hashmap for aggregation is empty.");
+    Batch result;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+      if (state->st.finish(result)) {
+        result.ctx = state->st.ctx;
+        *out = new qe_batch{result};
+        return;
+      }
+      // the table overflowed: a larger one, and everything seen so far folded in again
+      state->hint = (int64_t)state->st.cap * 4;
+      state->st.start(state->hint);
+      for (auto &b : state->history) state->st.update(b, {}, nullptr);
+    }
+    fail(QE_ERR_AGG_CAPACITY, "group table still full after growing");
+  });
+}
+
+void qe_agg_state_free(qe_agg_state *state) { delete state; }
 
 qe_status qe_plan_to_string(const qe_plan *plan, char *buf, int64_t buf_len, int64_t *needed) {
   return guarded([&] {

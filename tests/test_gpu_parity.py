@@ -440,3 +440,39 @@ def test_c_abi_from_plain_c():
     r = subprocess.run([exe, "3000001"], capture_output=True, text=True, timeout=100)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "C ABI example ok" in r.stdout and "Aggregate:" in r.stdout
+
+
+def test_streaming_accumulator_protocol(qe, ctx):
+    """qe_agg_state_new / qe_agg_update / qe_agg_finalize (the Accumulator protocol,
+    physical_expressions.rs:351-362) against the one-shot AggregateExec and the oracle: batches fed
+    one by one, a running result in between, and a group table that outgrows its hint."""
+    rng = np.random.default_rng(21)
+    n, parts = 300_000, 3
+    keys = rng.integers(0, 5000, n).astype(np.int64)
+    vals = rng.standard_normal(n)
+    valid = rng.random(n) > 0.1
+    C = qe.ColumnExpression
+    aggs = lambda m: [m.SumExpression(m.ColumnExpression(1)), m.CountExpression(m.ColumnExpression(1)), m.MaxExpression(m.ColumnExpression(1))]
+    batches = []
+    for p in range(parts):
+        sl = slice(p * n // parts, (p + 1) * n // parts)
+        batches.append(qe.Batch.from_numpy(ctx, [qe.Column(qe.TYPE_INT64, keys[sl]), qe.Column(qe.TYPE_FLOAT64, vals[sl], valid[sl])]).to_device())
+    state = qe.AggregationState(ctx, [C(0)], aggs(qe), group_capacity_hint=64)  # 5000 groups: the table has to grow
+    state.accumulate(batches[0])
+    first = state.final_value()
+    assert first.num_rows == len(np.unique(keys[: n // parts]))
+    for b in batches[1:]:
+        state.accumulate(b)
+    got = state.final_value().columns()
+    state.close()
+    chunk = orc.Chunk([orc.Array(orc.INT64, keys), orc.Array(orc.FLOAT64, vals, valid)])
+    want = list(orc.AggregateExec(orc.ScanExec([chunk]), [orc.ColumnExpression(0)], aggs(orc)).execute())[0].arrays
+    og, ow = np.argsort(np.asarray(got[0].values)), np.argsort(want[0].values)
+    assert np.array_equal(np.asarray(got[0].values)[og], want[0].values[ow])
+    assert np.allclose(np.asarray(got[1].values)[og], want[1].values[ow], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(np.asarray(got[2].values)[og], want[2].values[ow])
+    assert np.array_equal(np.asarray(got[3].values)[og], want[3].values[ow])
+    empty = qe.AggregationState(ctx, [C(0)], aggs(qe))
+    with pytest.raises(qe.QeError) as e:  # no batch at all: physical_plan/mod.rs:377
+        empty.final_value()
+    assert e.value.name == "EmptyHashmapForAggregate"
