@@ -16,7 +16,12 @@ import csv,glob,collections
 agg=collections.defaultdict(list)
 for f in glob.glob("$O/p*/pmc_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "qe_aggregate" in r["Kernel_Name"] or "qe_filter" in r["Kernel_Name"] or "qe_project" in r["Kernel_Name"]:
+        if "qe_" in r["Kernel_Name"]:
             agg[(r["Kernel_Name"][:60],r["Counter_Name"])].append(float(r["Counter_Value"]))
-for k,v in sorted(agg.items()): print(k[0],k[1],len(v),sum(v)/len(v))
+import json
+out={}
+for k,v in sorted(agg.items()):
+    print(k[0],k[1],len(v),sum(v)/len(v))
+    out.setdefault(k[0],{})[k[1]]={"launches":len(v),"mean_per_launch":sum(v)/len(v)}
+json.dump({"config":"$CFG","rows_per_launch":256000000,"counters":out},open("$O/summary.json","w"),indent=1)
 PY
