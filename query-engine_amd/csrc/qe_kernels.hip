@@ -427,7 +427,8 @@ __global__ void qe_table_init_kernel(AggTable T, uint64_t packed_lo, uint64_t pa
   if (blockIdx.x == 0 && threadIdx.x < 8) T.ctrl[threadIdx.x] = 0;
 }
 
-__global__ __launch_bounds__(256) void qe_finalize_kernel(const FinalizeArgs A) {
+// Small tables: one atomic per wave is few enough, and no barriers.
+__global__ __launch_bounds__(256) void qe_finalize_small_kernel(const FinalizeArgs A) {
   const AggTable &T = A.table;
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= T.cap;
        i += (uint64_t)gridDim.x * blockDim.x) {
@@ -482,6 +483,93 @@ __global__ __launch_bounds__(256) void qe_finalize_kernel(const FinalizeArgs A) 
         ((uint64_t *)f.values)[pos] = val;
       if (f.validity && valid) atomicOr(f.validity + (pos >> 5), 1u << (pos & 31u));
     }
+  }
+}
+
+// Output position of every occupied slot: one atomic per tile of 1024 slots (counts per wave and
+// item meet in LDS), not one per slot or per wave - a million groups would otherwise queue tens of
+// thousands of atomics on the one counter.
+constexpr int FIN_ITEMS = 4;
+
+__global__ __launch_bounds__(256) void qe_finalize_kernel(const FinalizeArgs A) {
+  const AggTable &T = A.table;
+  __shared__ uint32_t s_count[FIN_ITEMS][4];
+  __shared__ unsigned long long s_base;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint64_t n_slots = T.cap + 1;
+  const uint64_t tile_slots = 256ull * FIN_ITEMS;
+  for (uint64_t tile = blockIdx.x * tile_slots; tile < n_slots; tile += (uint64_t)gridDim.x * tile_slots) {
+    unsigned long long key[FIN_ITEMS];
+    uint64_t occ[FIN_ITEMS];
+#pragma unroll
+    for (int j = 0; j < FIN_ITEMS; ++j) {
+      const uint64_t i = tile + (uint64_t)j * 256 + threadIdx.x;
+      key[j] = i < n_slots ? T.keys[i] : AGG_EMPTY_KEY;
+      occ[j] = __ballot(key[j] != AGG_EMPTY_KEY);
+      if ((threadIdx.x & 63) == 0) s_count[j][wave] = (uint32_t)__popcll(occ[j]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t total = 0;
+      for (int j = 0; j < FIN_ITEMS; ++j)
+        for (int w = 0; w < 4; ++w) total += s_count[j][w];
+      s_base = total ? atomicAdd(A.out_count, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < FIN_ITEMS; ++j) {
+      const uint64_t i = tile + (uint64_t)j * 256 + threadIdx.x;
+      unsigned long long k = key[j];
+      if (k == AGG_EMPTY_KEY) continue;
+      uint32_t before = 0;
+      for (int jj = 0; jj < FIN_ITEMS; ++jj)
+        for (int w = 0; w < 4; ++w)
+          if (jj < j || (jj == j && (uint32_t)w < wave)) before += s_count[jj][w];
+      if (i == T.cap) k = AGG_EMPTY_KEY;  // reserved slot holds the marker-valued key
+      const unsigned long long pos = s_base + before + mbcnt64(occ[j]);
+      for (int o = 0; o < A.n_outs; ++o) {
+        const FinOut &f = A.outs[o];
+        uint64_t val = 0;
+        bool valid = true;
+        unsigned long long cnt = f.cnt_src == CNT_ROWS  ? T.rowcnt[i]
+                                 : f.cnt_src == CNT_NN ? T.nn[(uint64_t)f.b * T.stride + i]
+                                                       : T.acc[(uint64_t)f.b * T.stride + i];
+        if (f.null_mode == NULL_IF_COUNT_ZERO && cnt == 0) valid = false;
+        if (f.null_mode == NULL_IF_ACC_ALL_ONES && T.acc[(uint64_t)f.a * T.stride + i] == ~0ull) valid = false;
+        if (f.null_mode == NULL_IF_ACC_ZERO && T.acc[(uint64_t)f.a * T.stride + i] == 0ull) valid = false;
+        switch (f.kind) {
+          case FIN_KEY: {
+            uint64_t fm = f.bits >= 64 ? ~0ull : ((1ull << f.bits) - 1ull);
+            val = (k >> f.shift) & fm;
+            if (f.type == VT_I32) val = (uint64_t)(int64_t)(int32_t)(uint32_t)val;
+            break;
+          }
+          case FIN_ACC_I64:
+          case FIN_ACC_F64:
+            val = T.acc[(uint64_t)f.a * T.stride + i];
+            break;
+          case FIN_ACC_ORD:
+            val = valid ? ord_inverse(T.acc[(uint64_t)f.a * T.stride + i], f.type) : 0;
+            break;
+          case FIN_COUNT:
+            val = cnt;
+            break;
+          case FIN_AVG:
+            val = valid ? d2u(u2d(T.acc[(uint64_t)f.a * T.stride + i]) / (double)cnt) : 0;
+            break;
+          default:
+            break;
+        }
+        if (f.type == VT_I32)
+          ((uint32_t *)f.values)[pos] = (uint32_t)val;
+        else if (f.type == VT_BOOL) {
+          if (val & 1u) atomicOr((uint32_t *)f.values + (pos >> 5), 1u << (pos & 31u));
+        } else
+          ((uint64_t *)f.values)[pos] = val;
+        if (f.validity && valid) atomicOr(f.validity + (pos >> 5), 1u << (pos & 31u));
+      }
+    }
+    __syncthreads();  // s_count / s_base are reused by the next tile
   }
 }
 
@@ -843,7 +931,11 @@ hipError_t launch_table_init(const AggTable &table, const VmAcc *accs, int n_acc
 }
 
 hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream) {
-  int grid = grid_for((int64_t)args.table.cap + 1, 256, 4096);
+  if (args.table.cap + 1 <= (1u << 16)) {
+    hipLaunchKernelGGL(qe_finalize_small_kernel, dim3(grid_for((int64_t)args.table.cap + 1, 256, 4096)), dim3(256), 0, stream, args);
+    return hipGetLastError();
+  }
+  int grid = grid_for((int64_t)args.table.cap + 1, 256 * FIN_ITEMS, 4096);
   hipLaunchKernelGGL(qe_finalize_kernel, dim3(grid), dim3(256), 0, stream, args);
   return hipGetLastError();
 }
