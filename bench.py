@@ -135,11 +135,16 @@ def main():
         cols = [column_as_tensor(torch, part.column_desc(i), qe) for i in range(3)]
         # the only collective of the plan: the exchange of the partial tables over xGMI
         if partitioned:
-            tables = [xch.exchange(cols)]
+            table = xch.exchange(cols)
+            scan = qe.ScanExec(ctx, [qe.Batch.from_torch(ctx, [c.to(dev) for c in table])] if table[0].shape[0] > 0 else [])
+            final = qe.final_plan(scan, 1, aggs(1), group_capacity_hint=max(64, 2 * args.groups // world))
         else:
-            tables = xch.exchange(cols)
-        parts = [qe.Batch.from_torch(ctx, [c.to(dev) for c in t]) for t in tables if t[0].shape[0] > 0]
-        final = qe.final_plan(qe.ScanExec(ctx, parts), 1, aggs(1), group_capacity_hint=hint if not partitioned else max(64, 2 * args.groups // world))
+            # every rank's table in one batch, rows no rank filled are zero: COUNT(*) > 0 keeps the real ones, and the
+            # FINAL aggregate merges all ranks in one launch with no trip to the host in between
+            merged = xch.exchange_merged(cols)
+            scan = qe.ScanExec(ctx, [qe.Batch.from_torch(ctx, [c.to(dev) for c in merged])])
+            real = qe.SelectionExec([scan], qe.GtExpression(C(2), qe.LiteralInt64Expression(0)))
+            final = qe.final_plan(real, 1, aggs(1), group_capacity_hint=hint)
         return list(final.execute())[0]
 
     def barrier():

@@ -856,22 +856,29 @@ struct AggState {
     ctx->bind();
     // empty input: `iter.next().ok_or(Error::EmptyHashmapForAggregate)` (physical_plan/mod.rs:377)
     if (!have_table) fail(QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE, "The hashmap for aggregation is empty.");
-    QE_HIP(hipMemcpyAsync(ctx->host_counters + 16, table.ctrl, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    ctx->sync();
-    unsigned long long n_groups = ctx->host_counters[16], overflow = ctx->host_counters[17];
-    if (overflow) return false;
-    if (n_groups == 0) fail(QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE, "The hashmap for aggregation is empty.");
+    // Small tables: the output columns are sized for every slot and the finalize pass is queued
+    // before the group count is known, so that one trip to the host serves both.  Large tables
+    // read the count first and allocate exactly.
+    const bool eager = table.cap + 1 <= (1u << 16);
+    unsigned long long n_groups = 0, overflow = 0;
+    if (!eager) {
+      QE_HIP(hipMemcpyAsync(ctx->host_counters + 16, table.ctrl, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+      ctx->sync();
+      n_groups = ctx->host_counters[16];
+      overflow = ctx->host_counters[17];
+      if (overflow) return false;
+      if (n_groups == 0) fail(QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE, "The hashmap for aggregation is empty.");
+    }
+    const int64_t capacity = eager ? (int64_t)table.cap + 1 : (int64_t)n_groups;
     // output assembly (physical_plan/mod.rs:375-488): key columns, then one column per aggregate
     FinalizeArgs fa{};
     fa.table = table;
     fa.n_outs = (int)spec.outs.size();
     result = Batch();
     result.ctx = ctx;
-    result.rows = (int64_t)n_groups;
     for (size_t i = 0; i < spec.outs.size(); ++i) {
       FinOut f = spec.outs[i];
-      Column c = make_fixed_column(ctx, f.type, (int64_t)n_groups, f.null_mode != NULL_NEVER, false);
-      finish_fixed_column(c, (int64_t)n_groups);
+      Column c = make_fixed_column(ctx, f.type, capacity, f.null_mode != NULL_NEVER, false);
       f.values = c.values->ptr;
       f.validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
       fa.outs[i] = f;
@@ -882,11 +889,21 @@ struct AggState {
     ctx->prof_begin("qe_finalize_kernel");
     QE_HIP(launch_finalize(fa, ctx->stream));
     ctx->prof_end();
+    if (eager) {
+      QE_HIP(hipMemcpyAsync(ctx->host_counters + 16, table.ctrl, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+      ctx->sync();
+      n_groups = ctx->host_counters[16];
+      overflow = ctx->host_counters[17];
+      if (overflow) return false;
+      if (n_groups == 0) fail(QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE, "The hashmap for aggregation is empty.");
+    }
+    result.rows = (int64_t)n_groups;
+    for (auto &c : result.cols) finish_fixed_column(c, (int64_t)n_groups);
     if (spec.utf8_key_out >= 0) {
       Column &ids = result.cols[spec.utf8_key_out];
       result.cols[spec.utf8_key_out] = utf8_gather_rows(ctx, key_sources, (const int64_t *)ids.values->ptr, (int64_t)n_groups);
     }
-    ctx->sync();
+    if (!eager) ctx->sync();
     return true;
   }
 };

@@ -3,10 +3,11 @@ aggregate produced (keys, then partial sums / counts / minima / maxima) and rece
 ranks, ready to be merged by a FINAL aggregate.  The row-parallel part of the plan (scan, selection,
 projection, partial aggregate) needs no communication at all; this is the only collective.
 
-Tables are tiny next to the scanned data (groups x columns x 8 bytes), so the exchange is two
-fixed-size all-gathers (one int64 payload that also carries the row count, one float64 payload) into
-preallocated buffers: no size negotiation, no allocation per step, and the same code runs over RCCL
-(`nccl` backend, device tensors) and over gloo (CPU tensors, used by the tests)."""
+Tables are tiny next to the scanned data (groups x columns x 8 bytes), so the exchange is one
+fixed-size all-gather (an int64 payload that carries the row count and every column, float64 columns
+as their bit patterns) into preallocated buffers: no size negotiation, no allocation per step, and
+the same code runs over RCCL (`nccl` backend, device tensors) and over gloo (CPU tensors, used by
+the tests)."""
 
 
 class PartialExchange:
@@ -17,46 +18,56 @@ class PartialExchange:
         for d in self.dtypes:
             if d not in (torch.int64, torch.float64):
                 raise ValueError("partial tables hold int64 and float64 columns only")
-        self.int_cols = [i for i, d in enumerate(self.dtypes) if d == torch.int64]
-        self.f64_cols = [i for i, d in enumerate(self.dtypes) if d == torch.float64]
-        # int payload: [count | column 0 | column 1 ...], each column max_groups long
-        self.int_len = 1 + len(self.int_cols) * max_groups
-        self.f64_len = max(1, len(self.f64_cols) * max_groups)
-        self.send_i = torch.zeros(self.int_len, dtype=torch.int64, device=device)
-        self.send_f = torch.zeros(self.f64_len, dtype=torch.float64, device=device)
-        self.recv_i = torch.zeros(world * self.int_len, dtype=torch.int64, device=device)
-        self.recv_f = torch.zeros(world * self.f64_len, dtype=torch.float64, device=device)
+        # One int64 payload per rank: [row count | column 0 | column 1 ...], each column max_groups long;
+        # float64 columns travel as their bit patterns.  Rows past the count are zero.
+        self.n_cols = len(self.dtypes)
+        self.len = 1 + self.n_cols * max_groups
+        self.send = torch.zeros(self.len, dtype=torch.int64, device=device)
+        self.recv = torch.zeros(world * self.len, dtype=torch.int64, device=device)
+        self.sent_rows = 0
 
-    def exchange(self, columns):
-        """columns: this rank's partial table, one 1-D tensor per column, equal lengths.
-        Returns, per rank, the list of column tensors (views into the receive buffers: valid until
-        the next call)."""
+    def _gather(self, columns, with_count):
+        torch = self.torch
         g = int(columns[0].shape[0]) if columns else 0
         if g > self.max_groups:
             raise RuntimeError(f"{g} groups do not fit the exchange buffer ({self.max_groups}); size it from the key domain")
-        if len(columns) != len(self.dtypes):
+        if len(columns) != self.n_cols:
             raise ValueError("column count differs from the exchange layout")
-        self.send_i[0] = g
-        for slot, c in enumerate(self.int_cols):
-            self.send_i[1 + slot * self.max_groups:1 + slot * self.max_groups + g].copy_(columns[c])
-        for slot, c in enumerate(self.f64_cols):
-            self.send_f[slot * self.max_groups:slot * self.max_groups + g].copy_(columns[c])
-        self.dist.all_gather_into_tensor(self.recv_i, self.send_i)
-        if self.f64_cols:
-            self.dist.all_gather_into_tensor(self.recv_f, self.send_f)
-        counts = self.recv_i[0::self.int_len][:self.world].tolist()
+        body = self.send[1:].view(self.n_cols, self.max_groups)
+        if g < self.sent_rows:
+            body[:, g:self.sent_rows].zero_()  # a shorter table than last time: clear what it leaves behind
+        self.sent_rows = g
+        for i, c in enumerate(columns):
+            body[i, :g].copy_(c.view(torch.int64) if c.dtype == torch.float64 else c)
+        if with_count:
+            self.send[0] = g
+        self.dist.all_gather_into_tensor(self.recv, self.send)
+
+    def _typed(self, t, i):
+        return t.view(self.torch.float64) if self.dtypes[i] == self.torch.float64 else t
+
+    def exchange(self, columns):
+        """columns: this rank's partial table, one 1-D tensor per column, equal lengths.
+        Returns, per rank, the list of column tensors (views into the receive buffer: valid until
+        the next call).  Reads the row counts back to the host (one synchronisation)."""
+        self._gather(columns, True)
+        per_rank = self.recv.view(self.world, self.len)
+        counts = per_rank[:, 0].tolist()
         tables = []
         for r in range(self.world):
-            gr = int(counts[r])
-            cols = [None] * len(self.dtypes)
-            for slot, c in enumerate(self.int_cols):
-                base = r * self.int_len + 1 + slot * self.max_groups
-                cols[c] = self.recv_i[base:base + gr]
-            for slot, c in enumerate(self.f64_cols):
-                base = r * self.f64_len + slot * self.max_groups
-                cols[c] = self.recv_f[base:base + gr]
-            tables.append(cols)
+            body = per_rank[r, 1:].view(self.n_cols, self.max_groups)
+            tables.append([self._typed(body[i, :int(counts[r])], i) for i in range(self.n_cols)])
         return tables
+
+    def exchange_merged(self, columns):
+        """Same exchange, without the trip to the host: returns one table of world x max_groups rows
+        (list of contiguous column tensors) in which the rows no rank filled are all zero.  A partial
+        table with a COUNT(*) column tells the two apart (count > 0), so the caller puts that
+        predicate under its FINAL aggregate and merges everything in one launch."""
+        self._gather(columns, False)
+        body = self.recv.view(self.world, self.len)[:, 1:].view(self.world, self.n_cols, self.max_groups)
+        merged = body.permute(1, 0, 2).reshape(self.n_cols, self.world * self.max_groups)  # one small copy
+        return [self._typed(merged[i], i) for i in range(self.n_cols)]
 
 
 def shard_range(total_rows, rank, world):

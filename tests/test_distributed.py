@@ -52,6 +52,20 @@ def _worker(rank, world, port, n, n_keys, max_groups, out_dir):
         chunks = [orc.Chunk([orc.Array(orc.INT64, t[0].numpy().copy()), orc.Array(orc.FLOAT64, t[1].numpy().copy()),
                              orc.Array(orc.INT64, t[2].numpy().copy())]) for t in tables if len(t[0])]
         merged = list(orc.AggregateExec([orc.ScanExec(chunks)], [C(0)], [orc.SumExpression(C(1)), orc.SumExpression(C(2))]).execute())[0]
+        # the variant that stays off the host: one table of world x max_groups rows, unfilled rows all zero,
+        # COUNT(*) > 0 under the merge tells them apart
+        for _ in range(2):
+            one = xch.exchange_merged(cols)
+        assert all(t.shape[0] == world * max_groups and t.is_contiguous() for t in one)
+        assert int((one[2] > 0).sum()) == sum(len(t[0]) for t in tables)
+        whole = orc.Chunk([orc.Array(orc.INT64, one[0].numpy().copy()), orc.Array(orc.FLOAT64, one[1].numpy().copy()),
+                           orc.Array(orc.INT64, one[2].numpy().copy())])
+        real = orc.SelectionExec([orc.ScanExec([whole])], orc.GtExpression(C(2), orc.LiteralInt64Expression(0)))
+        again = list(orc.AggregateExec([real], [C(0)], [orc.SumExpression(C(1)), orc.SumExpression(C(2))]).execute())
+        if chunks:
+            o1, o2 = np.argsort(merged.arrays[0].values), np.argsort(again[0].arrays[0].values)
+            for x, y in zip(merged.arrays, again[0].arrays):
+                assert np.array_equal(x.values[o1], y.values[o2])
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), k=merged.arrays[0].values, s=merged.arrays[1].values, c=merged.arrays[2].values)
     finally:
         dist.destroy_process_group()
@@ -142,4 +156,8 @@ def test_exchange_rejects_oversized_table():
     assert t[0].tolist() == [0, 1, 2] and t[1].tolist() == [1.0, 1.0, 1.0]
     with pytest.raises(RuntimeError):
         x.exchange([torch.arange(5), torch.ones(5, dtype=torch.float64)])
+    # a shorter table after a longer one leaves nothing of the longer one behind
+    x.exchange([torch.arange(4) + 1, torch.ones(4, dtype=torch.float64)])
+    k, v = x.exchange_merged([torch.arange(2) + 7, torch.full((2,), 2.0, dtype=torch.float64)])
+    assert k.tolist() == [7, 8, 0, 0] and v.tolist() == [2.0, 2.0, 0.0, 0.0]
     assert d.shard_range(10, 0, 3) == (0, 3) and d.shard_range(10, 2, 3) == (6, 10)

@@ -8,11 +8,11 @@ QE_BENCH_BACKEND=gloo timeout -k 10 300 python3 -m torch.distributed.run --nnode
   $R/bench.py --gpus 2 --steps 3 --warmup 1 --rows 400000000 --groups $G > $R/gpurun_out/bench_n2_gloo_$G.json 2> $R/gpurun_out/bench_n2_gloo_$G.err || { tail -30 $R/gpurun_out/bench_n2_gloo_$G.err; exit 1; }
 python3 -c "
 import json,sys
-d=json.load(open('$R/gpurun_out/bench_n2_gloo_$G.json'))
+d=json.loads(open('$R/gpurun_out/bench_n2_gloo_$G.json').read().strip().splitlines()[-1])
 print('N=2 G=$G', d['value'], d['ms_per_step'], d['result_groups'], d['result_count_total'], d['config']['merge'])"
 timeout -k 10 300 python3 -u $R/bench.py --steps 3 --warmup 1 --rows 400000000 --groups $G --no-extra --no-cpu > $R/gpurun_out/bench_n1_$G.json 2>> $R/gpurun_out/bench_n2_gloo_$G.err || exit 1
 python3 -c "
 import json,sys
-d=json.load(open('$R/gpurun_out/bench_n1_$G.json'))
+d=json.loads(open('$R/gpurun_out/bench_n1_$G.json').read().strip().splitlines()[-1])
 print('N=1 G=$G', d['value'], d['ms_per_step'], d['result_groups'], d['result_count_total'])"
 done
