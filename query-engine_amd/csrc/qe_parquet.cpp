@@ -552,7 +552,10 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
       have_dict = true;
       dict_off = body;
       dict_count = h.num_values;
-      if (col.physical == PQ_BYTE_ARRAY) walks.push_back(PqWalk{body, body_len, -1, -1, dict_count});
+      if (col.physical == PQ_BYTE_ARRAY) {
+        if ((uint64_t)dict_count * 4 > body_len) bad_file("corrupt dictionary page");  // every entry has a 4-byte length
+        walks.push_back(PqWalk{body, body_len, -1, -1, dict_count});
+      }
       else {
         const uint64_t w = col.physical == PQ_INT32 ? 4 : col.physical == PQ_INT96 ? 12 : 8;
         if (col.physical == PQ_BOOLEAN || (uint64_t)dict_count * w > body_len) bad_file("corrupt dictionary page");
@@ -721,9 +724,13 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
     BufferPtr tmp = device_buffer(ctx, scan_scratch_elems(n_rows + 1) * 4 + 64);
     QE_HIP(launch_exclusive_scan_i32(offs, n_rows + 1, (int32_t *)tmp->ptr, ctx->stream));
     QE_HIP(hipMemcpyAsync(ctx->host_counters + 8, offs + n_rows, 4, hipMemcpyDeviceToHost, ctx->stream));
+    QE_HIP(hipMemcpyAsync(ctx->host_counters + 10, err, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    QE_HIP(hipMemsetAsync(err + 1, 0, sizeof(unsigned long long), ctx->stream));
     ctx->sync();
+    if (ctx->host_counters[10]) bad_file("column `" + col.name + "`: page contents contradict their headers");
+    if (ctx->host_counters[11] > 2147483647ull)
+      fail(QE_ERR_ARROW, "Arrow error: parquet: column `" + col.name + "` exceeds int32 offsets in one row group");
     const int32_t bytes = *(int32_t *)(ctx->host_counters + 8);
-    if (bytes < 0) fail(QE_ERR_ARROW, "Arrow error: parquet: column `" + col.name + "` exceeds int32 offsets in one row group");
     out.values_bytes = bytes;
     out.values = device_buffer(ctx, (size_t)bytes + 16);
     ctx->prof_begin("qe_parquet_utf8_copy_kernel");
@@ -860,7 +867,7 @@ Batch parquet_read_row_group(Context *ctx, ParquetFile &file, int row_group, con
     QE_HIP(hipHostMalloc((void **)&ctx->host_counters, 64 * sizeof(unsigned long long), hipHostMallocDefault));
   }
   unsigned long long *err = ctx->counters + 32;
-  QE_HIP(hipMemsetAsync(err, 0, sizeof(unsigned long long), ctx->stream));
+  QE_HIP(hipMemsetAsync(err, 0, 2 * sizeof(unsigned long long), ctx->stream));
   for (int c : columns) {
     if (c < 0 || c >= (int)file.columns.size()) fail(QE_ERR_EXCEEDING_BOUNDS, "column index out of range");
     b.cols.push_back(decode_chunk(ctx, file, file.columns[c], rg.chunks[c], rg.num_rows));

@@ -45,7 +45,7 @@ struct PqChunk {
   int32_t physical;           // PqPhysical
   uint32_t dict_off;          // image offset of the dictionary page's values (fixed width types)
   int32_t dict_count;
-  unsigned long long *error;  // set non-zero when the bytes contradict the descriptors
+  unsigned long long *error;  // [0] set non-zero when the bytes contradict the descriptors; [1] += string bytes of the column
 };
 
 // Definition levels (bit width 1) -> validity words + the number of valid rows per word.

@@ -152,6 +152,7 @@ __global__ void qe_parquet_walk_kernel(PqChunk c, const PqWalk *walks, int n_wal
 __global__ __launch_bounds__(256) void qe_parquet_utf8_rows_kernel(PqChunk c, const uint32_t *value_off, const int32_t *value_len,
                                                                    const uint32_t *dict_entry_off, const int32_t *dict_entry_len,
                                                                    uint32_t *row_src, int32_t *row_len) {
+  unsigned long long total = 0;
   for (int64_t r64 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r64 < c.n_rows; r64 += (int64_t)gridDim.x * blockDim.x) {
     const int row = (int)r64;
     uint32_t src = 0;
@@ -174,7 +175,12 @@ __global__ __launch_bounds__(256) void qe_parquet_utf8_rows_kernel(PqChunk c, co
     }
     row_src[row] = src;
     row_len[row] = len;
+    total += (unsigned long long)(uint32_t)len;
   }
+  // 64-bit sum of the lengths next to the error flag: the offsets are int32, the host refuses a
+  // column whose bytes do not fit them before anything is copied
+  for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
+  if ((threadIdx.x & 63) == 0 && total) atomicAdd(c.error + 1, total);
 }
 
 // Eight lanes per row: short strings dominate, and eight byte lanes keep a wave's stores within

@@ -273,3 +273,40 @@ def test_errors(qe, ctx, tmp_path):
     cut.write_bytes(data[:50000] + data[-2000:])
     with pytest.raises(qe.QeError):
         list(qe.ParquetScanExec(ctx, str(cut)).execute())
+
+
+def test_corrupted_files_fail_cleanly(qe, ctx, tmp_path):
+    """Random damage to the fixture and to a compressed, dictionary-encoded file: every scan either
+    fails with an engine error or returns batches with the file's row count - no crash, no hang, and
+    the device bounds checks (not luck) are what keeps the kernels inside their buffers."""
+    import pyarrow.parquet as pq
+    second = str(tmp_path / "second.parquet")
+    pq.write_table(sample_table(3000, seed=4), second, compression="snappy", data_page_size=2048, data_page_version="2.0")
+    rng = np.random.default_rng(11)
+    outcomes = {"ok": 0, "error": 0}
+    for source in (USERDATA, second):
+        data = bytearray(open(source, "rb").read())
+        rows = qe.parquet_schema(source)["rows"]
+        for trial in range(60):
+            bad = bytearray(data)
+            for _ in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(4, len(bad) - 8))
+                if trial % 3 == 0:
+                    bad[pos] ^= 1 << int(rng.integers(0, 8))          # a flipped bit
+                elif trial % 3 == 1:
+                    bad[pos:pos + 4] = bytes(rng.integers(0, 256, 4, dtype=np.uint8))  # four random bytes
+                else:
+                    bad[pos] = 0xFF
+            path = tmp_path / f"bad_{trial}.parquet"
+            path.write_bytes(bytes(bad))
+            try:
+                got = list(qe.ParquetScanExec(ctx, str(path)).execute())
+                assert sum(b.num_rows for b in got) == rows
+                for b in got:
+                    b.columns()  # copies everything back: offsets and bytes must be consistent
+                outcomes["ok"] += 1
+            except qe.QeError as e:
+                assert e.name in ("ArrowError", "IoError", "PhysicalTypeNotSuported", "ExceedingBoundsError", "OutOfMemory"), e
+                outcomes["error"] += 1
+            path.unlink()
+    assert outcomes["error"] > 0 and outcomes["ok"] + outcomes["error"] == 120
