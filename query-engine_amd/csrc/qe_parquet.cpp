@@ -681,10 +681,19 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
     // validity: the Arrow bitmap itself (64 rows per word), and the rank table the value kernels need
     out.validity = device_buffer(ctx, std::max(bitmap_bytes(n_rows), n_words * 8 + 32));
     QE_HIP(hipMemsetAsync(out.validity->ptr, 0, out.validity->bytes, ctx->stream));
-    word_rank = device_buffer(ctx, (n_words + 1) * 4 + 64);
-    QE_HIP(hipMemsetAsync(word_rank->ptr, 0, (n_words + 1) * 4, ctx->stream));
-    out.null_count = -1;
-    if (n_rows) {
+    // An optional column without a single null is the common case (writers mark columns optional by
+    // default): its levels are nothing but repeated runs of 1, which the host has just walked.  The
+    // bitmap is then a fill, and the value kernels address values by row, as for a required column.
+    bool all_valid = true;
+    for (const PqRun &r : level_runs) all_valid = all_valid && !r.packed && r.data == 1u;
+    if (all_valid) {
+      out.null_count = 0;
+      if (n_rows / 8) QE_HIP(hipMemsetAsync(out.validity->ptr, 0xff, (size_t)(n_rows / 8), ctx->stream));
+      if (n_rows % 8) QE_HIP(hipMemsetAsync((uint8_t *)out.validity->ptr + n_rows / 8, (1 << (n_rows % 8)) - 1, 1, ctx->stream));
+    } else {
+      word_rank = device_buffer(ctx, (n_words + 1) * 4 + 64);
+      QE_HIP(hipMemsetAsync(word_rank->ptr, 0, (n_words + 1) * 4, ctx->stream));
+      out.null_count = -1;
       ctx->prof_begin("qe_parquet_validity_kernel");
       QE_HIP(launch_pq_validity(d, (const PqRun *)(d + level_runs_at), (int)level_runs.size(), (int32_t)n_rows, (uint64_t *)out.validity->ptr,
                                 (int32_t *)word_rank->ptr, ctx->stream));

@@ -179,8 +179,15 @@ __global__ __launch_bounds__(256) void qe_parquet_utf8_rows_kernel(PqChunk c, co
   }
   // 64-bit sum of the lengths next to the error flag: the offsets are int32, the host refuses a
   // column whose bytes do not fit them before anything is copied
+  // (one atomic per workgroup: every wave drawing on the one counter would queue up behind it)
+  __shared__ unsigned long long s_total[4];
   for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
-  if ((threadIdx.x & 63) == 0 && total) atomicAdd(c.error + 1, total);
+  if ((threadIdx.x & 63) == 0) s_total[threadIdx.x >> 6] = total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = s_total[0] + s_total[1] + s_total[2] + s_total[3];
+    if (t) atomicAdd(c.error + 1, t);
+  }
 }
 
 // Eight lanes per row: short strings dominate, and eight byte lanes keep a wave's stores within
@@ -229,7 +236,7 @@ hipError_t launch_pq_walk(const PqChunk &chunk, const PqWalk *walks, int n_walks
 hipError_t launch_pq_utf8_rows(const PqChunk &chunk, const uint32_t *value_off, const int32_t *value_len, const uint32_t *dict_entry_off,
                                const int32_t *dict_entry_len, uint32_t *row_src, int32_t *row_len, hipStream_t stream) {
   if (chunk.n_rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(qe_parquet_utf8_rows_kernel, dim3(grid_rows(chunk.n_rows, 256, 8192)), dim3(256), 0, stream, chunk, value_off, value_len,
+  hipLaunchKernelGGL(qe_parquet_utf8_rows_kernel, dim3(grid_rows(chunk.n_rows, 256, 2048)), dim3(256), 0, stream, chunk, value_off, value_len,
                      dict_entry_off, dict_entry_len, row_src, row_len);
   return hipGetLastError();
 }
