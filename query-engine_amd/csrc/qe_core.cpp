@@ -168,6 +168,16 @@ Schema schema_of(const Batch &b) {
   return s;
 }
 
+Batch without_redundant_validity(const Batch &b) {
+  Batch out = b;
+  for (auto &c : out.cols)
+    if (c.known_all_valid && c.validity) {
+      c.validity.reset();
+      c.null_count = 0;
+    }
+  return out;
+}
+
 // ------------------------------------------------------------- expressions
 ExprPtr make_column(int index) {
   auto e = std::make_shared<Expr>();

@@ -86,6 +86,9 @@ struct Column {
   int space = QE_MEM_DEVICE;
   int64_t length = 0;
   int64_t null_count = 0;  // -1 = not counted yet
+  // Set by a producer that has seen every row valid although the column carries a validity buffer (an
+  // optional Parquet column without nulls): kernels may then leave the bitmap alone.
+  bool known_all_valid = false;
   BufferPtr validity, offsets, values;
   int64_t values_bytes = 0;
   const void *values_ptr() const { return values ? values->ptr : nullptr; }
@@ -152,6 +155,8 @@ struct ColInfo {
 };
 using Schema = std::vector<ColInfo>;
 Schema schema_of(const Batch &b);
+// The batch with the validity buffers dropped from columns known to hold no nulls.
+Batch without_redundant_validity(const Batch &b);
 
 // Type of the value an expression evaluates to over `schema`; throws the
 // reference's error for out-of-range columns / unsupported operand types.

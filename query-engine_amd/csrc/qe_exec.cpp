@@ -289,7 +289,8 @@ static Batch run_pipeline(Context *ctx, const Batch &in, const std::vector<ExprP
   return out;
 }
 
-static Batch run_pipeline_typed(Context *ctx, const Batch &in, const std::vector<ExprPtr> &outputs_raw, const ExprPtr &pred_raw) {
+static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::vector<ExprPtr> &outputs_raw, const ExprPtr &pred_raw) {
+  const Batch in = without_redundant_validity(in_raw);
   ctx->bind();
   const int64_t n = in.rows;
   Schema schema = schema_of(in);
@@ -750,8 +751,14 @@ static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &
 // Aggregation state fed one batch at a time: the device group table and what is needed to turn it
 // into the output batch.  AggregateExec::execute's loop body (physical_plan/mod.rs:298-374) is
 // `update`, its output assembly (:375-488) is `finish`.
+// Thrown by AggState::update when a batch needs null tracking that the table, set up from earlier
+// batches whose redundant validity buffers were ignored, does not have: the caller starts over with
+// `strict` set, which takes every validity buffer at face value.
+struct NeedsStrictNullability {};
+
 struct AggState {
   Context *ctx = nullptr;
+  bool strict = false;
   std::vector<ExprPtr> groups;  // over the columns `outputs` describes (or the batch's own, when empty)
   std::vector<AggExpr> aggs;
   int mode = QE_AGG_MODE_SINGLE;
@@ -780,7 +787,8 @@ struct AggState {
 
   // Folds one batch in.  `outputs` (may be empty = the batch's columns) are the expressions the
   // group / aggregate expressions' column indices refer to; `pred` selects rows.
-  void update(const Batch &in, const std::vector<ExprPtr> &outputs, const ExprPtr &pred) {
+  void update(const Batch &in_raw, const std::vector<ExprPtr> &outputs, const ExprPtr &pred) {
+    const Batch in = strict ? in_raw : without_redundant_validity(in_raw);
     ctx->bind();
     ensure_counters(ctx);
     std::vector<ExprPtr> src_outs = outputs;
@@ -828,11 +836,17 @@ struct AggState {
       for (size_t i = 0; same && i < spec.accs.size(); ++i)
         same = bspec.accs[i].acc.op == spec.accs[i].acc.op && bspec.accs[i].acc.in_type == spec.accs[i].acc.in_type;
       for (size_t i = 0; same && i < spec.keys.size(); ++i) same = bspec.keys[i].type == spec.keys[i].type;
-      if (!same) fail(QE_ERR_INVALID_ARGUMENT, "batches of one scan must share a schema");
+      if (!same) {
+        // nullability shapes the accumulator list (COUNT(x) of a column without nulls is the row count)
+        if (!strict) throw NeedsStrictNullability{};
+        fail(QE_ERR_INVALID_ARGUMENT, "batches of one scan must share a schema");
+      }
       // a later batch may be nullable where the first was not: keep the stricter tracking
       for (size_t i = 0; i < spec.accs.size(); ++i)
-        if (bspec.accs[i].acc.track_nn && !spec.accs[i].acc.track_nn)
+        if (bspec.accs[i].acc.track_nn && !spec.accs[i].acc.track_nn) {
+          if (!strict) throw NeedsStrictNullability{};
           fail(QE_ERR_INVALID_ARGUMENT, "batches of one scan must share nullability");
+        }
     }
     if (in.rows == 0) return;
     Compiler comp(ctx, &in);
@@ -926,11 +940,16 @@ struct AggIter : Iter {
     st.mode = mode;
     st.cap_hint = cap_hint;
     int64_t hint = cap_hint > 0 ? cap_hint : 32768;
-    for (int attempt = 0; attempt < 6; ++attempt) {
+    for (int attempt = 0; attempt < 7; ++attempt) {
       st.start(hint);
       s.src->reset();
       Batch in;
-      while (s.src->next(in)) st.update(in, stream_outputs(s, (int)in.cols.size()), s.pred);
+      try {
+        while (s.src->next(in)) st.update(in, stream_outputs(s, (int)in.cols.size()), s.pred);
+      } catch (const NeedsStrictNullability &) {
+        st.strict = true;  // a later batch has nulls where the earlier ones had none: once more, tracking them
+        continue;
+      }
       if (st.finish(result)) {
         done = true;
         return;
@@ -1739,7 +1758,14 @@ qe_status qe_agg_update(qe_agg_state *state, const qe_batch *batch) {
       state->st.start(state->hint);
       state->started = true;
     }
-    state->st.update(batch->b, {}, nullptr);
+    try {
+      state->st.update(batch->b, {}, nullptr);
+    } catch (const NeedsStrictNullability &) {
+      state->st.strict = true;
+      state->st.start(state->hint);
+      for (auto &b : state->history) state->st.update(b, {}, nullptr);
+      state->st.update(batch->b, {}, nullptr);
+    }
     state->history.push_back(batch->b);
   });
 }

@@ -688,6 +688,7 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
     for (const PqRun &r : level_runs) all_valid = all_valid && !r.packed && r.data == 1u;
     if (all_valid) {
       out.null_count = 0;
+      out.known_all_valid = true;
       if (n_rows / 8) QE_HIP(hipMemsetAsync(out.validity->ptr, 0xff, (size_t)(n_rows / 8), ctx->stream));
       if (n_rows % 8) QE_HIP(hipMemsetAsync((uint8_t *)out.validity->ptr + n_rows / 8, (1 << (n_rows % 8)) - 1, 1, ctx->stream));
     } else {

@@ -310,3 +310,40 @@ def test_corrupted_files_fail_cleanly(qe, ctx, tmp_path):
                 outcomes["error"] += 1
             path.unlink()
     assert outcomes["error"] > 0 and outcomes["ok"] + outcomes["error"] == 120
+
+
+def test_nulls_only_in_a_later_row_group(qe, ctx, tmp_path):
+    """Optional columns whose first row group has no nulls are aggregated without null tracking; a
+    later row group with nulls makes the aggregate start over with tracking.  Same result as the oracle."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    n = 40_000
+    rng = np.random.default_rng(13)
+    mask = np.zeros(n, dtype=bool)
+    mask[n // 2:] = rng.random(n // 2) < 0.2  # nulls in the second half only
+    tbl = pa.table({"k": pa.array(rng.integers(0, 7, n)), "v": pa.array(rng.standard_normal(n), mask=mask)})
+    path = str(tmp_path / "late_nulls.parquet")
+    pq.write_table(tbl, path, row_group_size=n // 2)
+    aggs = lambda m: [m.SumExpression(m.ColumnExpression(1)), m.CountExpression(m.ColumnExpression(1)), m.MinExpression(m.ColumnExpression(1))]
+    got = list(qe.AggregateExec(qe.ParquetScanExec(ctx, path), [qe.ColumnExpression(0)], aggs(qe)).execute())[0].columns()
+    chunks = list(porc.ParquetFile(path).scan())
+    assert chunks[0].arrays[1].validity.all() and not chunks[1].arrays[1].validity.all()
+    want = list(orc.AggregateExec(orc.ScanExec(chunks), [orc.ColumnExpression(0)], aggs(orc)).execute())[0].arrays
+    og, ow = np.argsort(np.asarray(got[0].values)), np.argsort(want[0].values)
+    assert np.array_equal(np.asarray(got[0].values)[og], want[0].values[ow])
+    assert np.allclose(np.asarray(got[1].values)[og], want[1].values[ow], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(np.asarray(got[2].values)[og], want[2].values[ow])
+    assert np.array_equal(np.asarray(got[3].values)[og], want[3].values[ow])
+    # the same through the accumulator protocol, batch by batch
+    state = qe.AggregationState(ctx, [qe.ColumnExpression(0)], aggs(qe))
+    for b in qe.ParquetScanExec(ctx, path).execute():
+        state.accumulate(b)
+    again = state.final_value().columns()
+    o2 = np.argsort(np.asarray(again[0].values))
+    assert np.array_equal(np.asarray(again[2].values)[o2], want[2].values[ow])
+    assert np.array_equal(np.asarray(again[3].values)[o2], want[3].values[ow])
+    # a filter over the all-valid row group still yields the right rows
+    sel = qe.SelectionExec(qe.ParquetScanExec(ctx, path), qe.GtExpression(qe.ColumnExpression(1), qe.LiteralFloatExpression(1.0)))
+    rows = sum(b.num_rows for b in sel.execute())
+    v = np.asarray(tbl.column("v").fill_null(0.0))
+    assert rows == int(((v > 1.0) & ~mask).sum())
