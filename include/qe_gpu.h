@@ -250,6 +250,12 @@ qe_status qe_plan_scan_memory(qe_context *ctx, qe_batch *const *batches, int32_t
  * QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED at execution when a scanned column has a
  * type outside QE_TYPE_*. */
 qe_status qe_plan_scan_parquet(qe_context *ctx, const char *path, const char *const *projection, int32_t n_projection, qe_plan **out);
+/* The same scan restricted to row groups [first_row_group, first_row_group +
+ * n_row_groups) of the file (clamped to what the file has): the unit by which a
+ * file is split over GPUs, one contiguous run of row groups per rank (no
+ * counterpart in the reference, which is single process). */
+qe_status qe_plan_scan_parquet_row_groups(qe_context *ctx, const char *path, const char *const *projection, int32_t n_projection,
+                                          int32_t first_row_group, int32_t n_row_groups, qe_plan **out);
 /* ParquetDataSource::schema (data_source.rs:45-47) as JSON, in the format of
  * qe_dataframe_schema, plus "rows" and "row_groups":
  * {"fields":[...],"rows":N,"row_groups":G}.  Needs no GPU. */

@@ -88,6 +88,8 @@ ABI = {
     "qe_agg_state_free": (None, [C.c_void_p]),
     "qe_plan_scan_memory": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]),
     "qe_plan_scan_parquet": (C.c_int32, [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_void_p)]),
+    "qe_plan_scan_parquet_row_groups": (C.c_int32, [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32,
+                                                    C.POINTER(C.c_void_p)]),
     "qe_parquet_schema": (C.c_int32, [C.c_char_p, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
     "qe_plan_projection": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]),
     "qe_plan_selection": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -683,17 +685,19 @@ class ParquetScanExec(PhysicalPlan):
     """ScanExec over DataSource::Parquet (physical_plan/mod.rs:68-110, data_source.rs:24-72): one
     device-resident batch per row group; `projection` = column names (None = all), file order."""
 
-    def __init__(self, ctx, path, projection=None):
+    def __init__(self, ctx, path, projection=None, row_groups=None):
+        """row_groups: (first, count) to scan a contiguous run of the file's row groups (one rank's share)."""
         super().__init__(ctx, [])
         self.path, self.projection = path, None if projection is None else list(projection)
+        self.first, self.count = (0, -1) if row_groups is None else row_groups
 
     def _build(self):
         h = C.c_void_p()
-        if self.projection is None:
-            _check(lib.qe_plan_scan_parquet(self.ctx._h, self.path.encode(), None, -1, C.byref(h)))
-        else:
-            names = (C.c_char_p * max(1, len(self.projection)))(*[n.encode() for n in self.projection])
-            _check(lib.qe_plan_scan_parquet(self.ctx._h, self.path.encode(), names, len(self.projection), C.byref(h)))
+        names, n = None, -1
+        if self.projection is not None:
+            names = (C.c_char_p * max(1, len(self.projection)))(*[x.encode() for x in self.projection])
+            n = len(self.projection)
+        _check(lib.qe_plan_scan_parquet_row_groups(self.ctx._h, self.path.encode(), names, n, self.first, self.count, C.byref(h)))
         return h
 
 

@@ -29,12 +29,13 @@ struct ScanIter : Iter {
   std::vector<Batch> batches;
   std::shared_ptr<ParquetFile> parquet;  // when set: one batch per row group, decoded on demand
   std::vector<int> parquet_columns;
+  size_t first = 0, end = 0;  // row groups of the file this scan covers
   size_t cur = 0;
   bool next(Batch &out) override {
     if (parquet) {
       // ScanIterator::next (physical_plan/mod.rs:99-109) over the file reader's row groups
-      if (cur >= parquet->row_groups.size()) return false;
-      out = parquet_read_row_group(ctx, *parquet, (int)cur++, parquet_columns);
+      if (first + cur >= end) return false;
+      out = parquet_read_row_group(ctx, *parquet, (int)(first + cur++), parquet_columns);
       return true;
     }
     if (cur >= batches.size()) return false;
@@ -979,6 +980,12 @@ static Stream build_stream(std::unique_ptr<Plan> plan) {
       it->batches = std::move(plan->batches);
       it->parquet = plan->parquet;
       it->parquet_columns = plan->parquet_columns;
+      if (plan->parquet) {
+        const size_t have = plan->parquet->row_groups.size();
+        it->first = std::min(have, (size_t)std::max(plan->parquet_first, 0));
+        it->end = plan->parquet_end < 0 ? have : std::min(have, (size_t)plan->parquet_end);
+        if (it->end < it->first) it->end = it->first;
+      }
       Stream s;
       s.src = std::move(it);
       return s;
@@ -1030,6 +1037,7 @@ static std::string plan_to_string(const Plan *p, int indent) {
         o << "Scan: " << p->parquet->path << "; projection=[";
         for (size_t i = 0; i < p->parquet_columns.size(); ++i) o << (i ? ", " : "") << p->parquet->columns[p->parquet_columns[i]].name;
         o << "], row_groups=" << p->parquet->row_groups.size();
+        if (p->parquet_end >= 0) o << " [" << p->parquet_first << ", " << p->parquet_end << ")";
       } else {
         o << "Scan: memory, batches=" << p->batches.size();
       }
@@ -1614,9 +1622,16 @@ qe_status qe_plan_scan_memory(qe_context *ctx, qe_batch *const *batches, int32_t
 }
 
 qe_status qe_plan_scan_parquet(qe_context *ctx, const char *path, const char *const *projection, int32_t n_projection, qe_plan **out) {
+  return qe_plan_scan_parquet_row_groups(ctx, path, projection, n_projection, 0, -1, out);
+}
+
+qe_status qe_plan_scan_parquet_row_groups(qe_context *ctx, const char *path, const char *const *projection, int32_t n_projection,
+                                          int32_t first_row_group, int32_t n_row_groups, qe_plan **out) {
   return guarded([&] {
-    QE_REQUIRE(ctx && out && path && (projection || n_projection <= 0), "bad arguments");
+    QE_REQUIRE(ctx && out && path && (projection || n_projection <= 0) && first_row_group >= 0, "bad arguments");
     auto p = std::make_unique<Plan>();
+    p->parquet_first = first_row_group;
+    p->parquet_end = n_row_groups < 0 ? -1 : first_row_group + n_row_groups;
     p->kind = PK_SCAN;
     p->ctx = &ctx->c;
     p->parquet = parquet_open(path);

@@ -20,6 +20,7 @@ struct Plan {
   std::vector<Batch> batches;        // scan over memory
   std::shared_ptr<ParquetFile> parquet;  // scan over a file: one batch per row group ...
   std::vector<int> parquet_columns;      // ... of these columns
+  int parquet_first = 0, parquet_end = -1;  // row groups [first, end); end < 0 = all the file has
   std::vector<ExprPtr> exprs;        // projection
   ExprPtr pred;                      // selection
   std::vector<ExprPtr> group_exprs;  // aggregate

@@ -347,3 +347,37 @@ def test_nulls_only_in_a_later_row_group(qe, ctx, tmp_path):
     rows = sum(b.num_rows for b in sel.execute())
     v = np.asarray(tbl.column("v").fill_null(0.0))
     assert rows == int(((v > 1.0) & ~mask).sum())
+
+
+def test_row_group_shards(qe, ctx, tmp_path):
+    """A file split over ranks by contiguous runs of row groups (distributed.shard_range over the row
+    group count): PARTIAL aggregates of the shards merged by a FINAL one equal the aggregate of the file."""
+    import importlib
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    D = importlib.import_module("query-engine_amd.distributed")
+    n = 50_000
+    rng = np.random.default_rng(17)
+    tbl = pa.table({"k": pa.array(rng.integers(0, 9, n)), "v": pa.array(rng.random(n))})
+    path = str(tmp_path / "shards.parquet")
+    pq.write_table(tbl, path, row_group_size=10_000)
+    groups = qe.parquet_schema(path)["row_groups"]
+    assert groups == 5
+    C = qe.ColumnExpression
+    aggs = lambda: [qe.SumExpression(C(1)), qe.CountExpression(None), qe.AvgExpression(C(1))]
+    world, partials, rows = 3, [], 0
+    for rank in range(world):
+        lo, hi = D.shard_range(groups, rank, world)
+        scan = qe.ParquetScanExec(ctx, path, row_groups=(lo, hi - lo))
+        rows += sum(b.num_rows for b in qe.ParquetScanExec(ctx, path, row_groups=(lo, hi - lo)).execute())
+        partials += list(qe.AggregateExec(scan, [C(0)], aggs(), mode=qe.AGG_MODE_PARTIAL).execute())
+    assert rows == n
+    assert sum(b.num_rows for b in qe.ParquetScanExec(ctx, path, row_groups=(4, 7)).execute()) == 10_000  # clamped to the file
+    assert list(qe.ParquetScanExec(ctx, path, row_groups=(9, 1)).execute()) == []
+    merged = list(qe.final_plan(qe.ScanExec(ctx, partials), 1, aggs()).execute())[0].columns()
+    whole = list(qe.AggregateExec(qe.ParquetScanExec(ctx, path), [C(0)], aggs()).execute())[0].columns()
+    om, ow = np.argsort(np.asarray(merged[0].values)), np.argsort(np.asarray(whole[0].values))
+    assert np.array_equal(np.asarray(merged[0].values)[om], np.asarray(whole[0].values)[ow])
+    assert np.allclose(np.asarray(merged[1].values)[om], np.asarray(whole[1].values)[ow], rtol=1e-12)
+    assert np.array_equal(np.asarray(merged[2].values)[om], np.asarray(whole[2].values)[ow])
+    assert np.allclose(np.asarray(merged[3].values)[om], np.asarray(whole[3].values)[ow], rtol=1e-12)
