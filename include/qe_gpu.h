@@ -113,7 +113,18 @@ enum {
    * with this flag the first launch of a shape compiles and waits, whatever the
    * batch size (tests, prepared workloads).  The environment variable QE_JIT =
    * off | async | sync sets the default. */
-  QE_FLAG_JIT_SYNC = 4
+  QE_FLAG_JIT_SYNC = 4,
+  /* Aggregates whose group table is small (at most 65536 slots, no utf8 key)
+   * hand back their output without waiting for the device to report how many
+   * groups there are: the batch has one row per table slot, the rows past the
+   * number of groups are all zero (a COUNT(*) column tells real rows apart:
+   * count > 0), and nothing in the call synchronises with the device, so a
+   * caller can queue step after step - partial aggregate, exchange, final
+   * merge - and let the host run ahead.  A table that overflows its
+   * `group_capacity_hint` cannot be regrown in this mode: the failure is
+   * reported by the next qe_context_synchronize (QE_ERR_AGG_CAPACITY).  No
+   * counterpart in the reference. */
+  QE_FLAG_DEFERRED_GROUP_COUNT = 8
 };
 
 typedef struct qe_context qe_context;
@@ -165,6 +176,8 @@ int32_t qe_device_count(void);
  * fallback behind this ABI. */
 qe_status qe_context_create(int32_t device, void *stream, qe_context **out);
 qe_status qe_context_set_flags(qe_context *ctx, uint32_t flags);
+/* Waits for everything queued on the context's stream; reports a deferred
+ * aggregate (QE_FLAG_DEFERRED_GROUP_COUNT) whose table overflowed since the last call. */
 qe_status qe_context_synchronize(qe_context *ctx);
 void qe_context_free(qe_context *ctx);
 

@@ -138,6 +138,38 @@ BufferPtr borrowed_buffer(const void *p, size_t bytes, int space) {
   return b;
 }
 
+BufferPtr sub_buffer(const BufferPtr &parent, size_t offset, size_t bytes) {
+  auto b = std::make_shared<Buffer>();
+  b->ptr = (uint8_t *)parent->ptr + offset;
+  b->bytes = bytes;
+  b->space = parent->space;
+  b->owned = false;
+  b->parent = parent;
+  return b;
+}
+
+unsigned long long *Context::deferred_sink() {
+  bind();
+  if (!counters) {
+    QE_HIP(hipMalloc((void **)&counters, 64 * sizeof(unsigned long long)));
+    QE_HIP(hipHostMalloc((void **)&host_counters, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+  }
+  if (!deferred_pending) {
+    QE_HIP(hipMemsetAsync(counters + 40, 0, sizeof(unsigned long long), stream));
+    deferred_pending = true;
+  }
+  return counters + 40;
+}
+
+void Context::check_deferred() {
+  if (!deferred_pending) return;
+  deferred_pending = false;
+  QE_HIP(hipMemcpyAsync(host_counters + 40, counters + 40, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+  sync();
+  if (host_counters[40])
+    fail(QE_ERR_AGG_CAPACITY, "a deferred aggregate overflowed its group table: give a larger group_capacity_hint or clear QE_FLAG_DEFERRED_GROUP_COUNT");
+}
+
 size_t bitmap_bytes(int64_t n) { return (size_t)((n + 255) / 256) * 32 + 32; }
 
 int type_width(int type) {

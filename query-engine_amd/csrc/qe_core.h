@@ -45,6 +45,11 @@ struct Context : std::enable_shared_from_this<Context> {
   };
   Staging staging[2];
   int next_staging = 0;
+  // Aggregates that returned before the device was done (QE_FLAG_DEFERRED_GROUP_COUNT) leave their
+  // overflow flag in one device word (their finalize kernel adds to it); the next synchronise reads it.
+  bool deferred_pending = false;
+  unsigned long long *deferred_sink();  // the device word
+  void check_deferred();                // with the stream idle: fails if any such aggregate overflowed
   unsigned long long *host_counters = nullptr;  // pinned mirror
   // profiling
   bool profiling = false;
@@ -73,6 +78,7 @@ struct Buffer {
   size_t actual = 0;  // pool bucket size (device, owned)
   int space = QE_MEM_HOST;
   bool owned = false;
+  std::shared_ptr<Buffer> parent;  // a view into another buffer keeps it alive
   ~Buffer();
 };
 using BufferPtr = std::shared_ptr<Buffer>;
@@ -80,6 +86,7 @@ using BufferPtr = std::shared_ptr<Buffer>;
 BufferPtr device_buffer(Context *ctx, size_t bytes);
 BufferPtr host_buffer(size_t bytes);
 BufferPtr borrowed_buffer(const void *p, size_t bytes, int space);
+BufferPtr sub_buffer(const BufferPtr &parent, size_t offset, size_t bytes);
 
 struct Column {
   int type = 0;

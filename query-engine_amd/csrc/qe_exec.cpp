@@ -772,9 +772,11 @@ struct AggState {
   BufferPtr table_buf;
   std::vector<Utf8KeySource> key_sources;
   int64_t row_base = 0;
+  int deferred_finishes = 0;
 
   // Fresh table for about `hint` groups.
   void start(int64_t hint) {
+    deferred_finishes = 0;
     cap = 1024;
     while (cap < (uint64_t)hint * 2) cap <<= 1;
     if (cap > (1ull << 30)) fail(QE_ERR_AGG_CAPACITY, "group table would exceed 2^30 slots");
@@ -866,6 +868,54 @@ struct AggState {
     if (!comp.keepalive.empty()) ctx->sync();
   }
 
+  // The output without a word from the device: one row per table slot, the rows past the group count
+  // all zero (values and validity), every column a slice of one zeroed block.  The control words
+  // travel to a pinned slot that the next synchronise examines.
+  bool finish_deferred(Batch &result) {
+    const int64_t capacity = (int64_t)table.cap + 1;
+    std::vector<size_t> at;
+    size_t total = 0;
+    for (auto &f : spec.outs) {
+      at.push_back(total);
+      total += (f.type == QE_TYPE_BOOLEAN ? bitmap_bytes(capacity) : (((size_t)capacity * type_width(f.type) + 16 + 255) & ~(size_t)255));
+      at.push_back(total);
+      if (f.null_mode != NULL_NEVER) total += (bitmap_bytes(capacity) + 255) & ~(size_t)255;
+    }
+    BufferPtr block = device_buffer(ctx, total + 256);
+    QE_HIP(hipMemsetAsync(block->ptr, 0, total, ctx->stream));
+    FinalizeArgs fa{};
+    fa.table = table;
+    fa.n_outs = (int)spec.outs.size();
+    result = Batch();
+    result.ctx = ctx;
+    result.rows = capacity;
+    for (size_t i = 0; i < spec.outs.size(); ++i) {
+      FinOut f = spec.outs[i];
+      Column c;
+      c.type = f.type;
+      c.space = QE_MEM_DEVICE;
+      c.length = capacity;
+      c.values_bytes = f.type == QE_TYPE_BOOLEAN ? (capacity + 7) / 8 : capacity * type_width(f.type);
+      c.values = sub_buffer(block, at[2 * i], (size_t)(at[2 * i + 1] - at[2 * i]));
+      if (f.null_mode != NULL_NEVER) {
+        c.validity = sub_buffer(block, at[2 * i + 1], bitmap_bytes(capacity));
+        c.null_count = -1;
+      }
+      f.values = c.values->ptr;
+      f.validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
+      fa.outs[i] = f;
+      result.cols.push_back(c);
+    }
+    // the finalize kernel draws output positions from a counter of its own: the table's spare control word
+    fa.out_count = table.ctrl + 2;
+    fa.overflow_sink = ctx->deferred_sink();
+    if (deferred_finishes++) QE_HIP(hipMemsetAsync(table.ctrl + 2, 0, sizeof(unsigned long long), ctx->stream));  // a running result came before
+    ctx->prof_begin("qe_finalize_kernel");
+    QE_HIP(launch_finalize(fa, ctx->stream));
+    ctx->prof_end();
+    return true;
+  }
+
   // The output batch.  False when the table overflowed: the caller starts over with a larger one.
   bool finish(Batch &result) {
     ctx->bind();
@@ -875,6 +925,7 @@ struct AggState {
     // before the group count is known, so that one trip to the host serves both.  Large tables
     // read the count first and allocate exactly.
     const bool eager = table.cap + 1 <= (1u << 16);
+    if (eager && (ctx->flags & QE_FLAG_DEFERRED_GROUP_COUNT) && spec.utf8_key_out < 0) return finish_deferred(result);
     unsigned long long n_groups = 0, overflow = 0;
     if (!eager) {
       QE_HIP(hipMemcpyAsync(ctx->host_counters + 16, table.ctrl, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -1344,6 +1395,7 @@ qe_status qe_context_synchronize(qe_context *ctx) {
     QE_REQUIRE(ctx, "ctx is null");
     ctx->c.bind();
     ctx->c.sync();
+    ctx->c.check_deferred();
   });
 }
 

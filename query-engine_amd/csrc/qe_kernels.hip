@@ -430,6 +430,7 @@ __global__ void qe_table_init_kernel(AggTable T, uint64_t packed_lo, uint64_t pa
 // Small tables: one atomic per wave is few enough, and no barriers.
 __global__ __launch_bounds__(256) void qe_finalize_small_kernel(const FinalizeArgs A) {
   const AggTable &T = A.table;
+  if (A.overflow_sink && blockIdx.x == 0 && threadIdx.x == 0 && T.ctrl[1]) atomicAdd(A.overflow_sink, 1ull);
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= T.cap;
        i += (uint64_t)gridDim.x * blockDim.x) {
     unsigned long long k = T.keys[i];

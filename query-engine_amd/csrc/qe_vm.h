@@ -164,7 +164,7 @@ struct AggTable {
   unsigned long long *rowcnt;
   unsigned long long *acc;  // acc[a * stride + slot]
   unsigned long long *nn;   // nn[a * stride + slot]
-  unsigned long long *ctrl; // [0] = groups claimed, [1] = overflow flag
+  unsigned long long *ctrl; // [0] = groups claimed, [1] = overflow flag, [2] = output rows drawn by a deferred finalize
   uint64_t cap;             // power of two
   uint64_t stride;          // cap + 1 rounded up to 64
 };
@@ -271,6 +271,7 @@ struct FinalizeArgs {
   int32_t n_outs;
   int32_t pad;
   unsigned long long *out_count;  // rows written
+  unsigned long long *overflow_sink;  // when set: incremented if the table's overflow flag is up (deferred checks)
 };
 
 }  // namespace qe

@@ -476,3 +476,57 @@ def test_streaming_accumulator_protocol(qe, ctx):
     with pytest.raises(qe.QeError) as e:  # no batch at all: physical_plan/mod.rs:377
         empty.final_value()
     assert e.value.name == "EmptyHashmapForAggregate"
+
+
+def test_deferred_group_count(qe, ctx):
+    """QE_FLAG_DEFERRED_GROUP_COUNT: the aggregate returns one row per table slot without waiting for
+    the device; rows with COUNT(*) > 0 are exactly the synchronous result; PARTIAL -> FINAL works on the
+    padded tables with that predicate; an overflowing table is reported by the next synchronise."""
+    rng = np.random.default_rng(31)
+    n = 200_000
+    keys = rng.integers(-20, 20, n).astype(np.int64)
+    vals = rng.standard_normal(n)
+    valid = rng.random(n) > 0.2
+    C = qe.ColumnExpression
+    batch = qe.Batch.from_numpy(ctx, [qe.Column(qe.TYPE_INT64, keys), qe.Column(qe.TYPE_FLOAT64, vals, valid)]).to_device()
+    aggs = lambda: [qe.SumExpression(C(1)), qe.CountExpression(None), qe.MinExpression(C(1)), qe.AvgExpression(C(1))]
+
+    def run(mode=qe.AGG_MODE_SINGLE, hint=64):
+        return list(qe.AggregateExec(qe.ScanExec(ctx, [batch]), [C(0)], aggs(), mode=mode, group_capacity_hint=hint).execute())[0]
+    want = run().columns()
+    default_flags = qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP
+    ctx.set_flags(default_flags | qe.FLAG_DEFERRED_GROUP_COUNT)
+    try:
+        padded = run()
+        assert padded.num_rows == 1025  # the smallest table: 1024 slots + the reserved one
+        ctx.synchronize()
+        got = padded.columns()
+        real = np.asarray(got[2].values) > 0
+        assert int(real.sum()) == len(want[0]) == 40
+        og, ow = np.argsort(np.asarray(got[0].values)[real]), np.argsort(np.asarray(want[0].values))
+        for g, w in zip(got, want):
+            gv, wv = np.asarray(g.values)[real][og], np.asarray(w.values)[ow]
+            assert np.allclose(gv, wv, rtol=1e-12, atol=1e-12) if gv.dtype == np.float64 else np.array_equal(gv, wv)
+        assert not np.asarray(got[1].values)[~real].any() and not np.asarray(got[0].values)[~real].any()
+        # PARTIAL (padded) -> FINAL with COUNT(*) > 0 underneath, nothing synchronised in between
+        part = run(mode=qe.AGG_MODE_PARTIAL)
+        first, _ = qe.partial_layout(1, aggs())
+        keep = qe.SelectionExec(qe.ScanExec(ctx, [part]), qe.GtExpression(C(first[1]), qe.LiteralInt64Expression(0)))
+        merged = list(qe.final_plan(keep, 1, aggs(), group_capacity_hint=64).execute())[0]
+        ctx.synchronize()
+        mc = merged.columns()
+        real = np.asarray(mc[2].values) > 0
+        om = np.argsort(np.asarray(mc[0].values)[real])
+        assert np.array_equal(np.asarray(mc[0].values)[real][om], np.asarray(want[0].values)[ow])
+        assert np.array_equal(np.asarray(mc[2].values)[real][om], np.asarray(want[2].values)[ow])
+        assert np.allclose(np.asarray(mc[4].values)[real][om], np.asarray(want[4].values)[ow], rtol=1e-12)
+        # too small a table cannot be regrown here: the next synchronise says so
+        wide = qe.Batch.from_numpy(ctx, [qe.Column(qe.TYPE_INT64, np.arange(5000, dtype=np.int64)), qe.Column(qe.TYPE_FLOAT64, np.ones(5000))]).to_device()
+        list(qe.AggregateExec(qe.ScanExec(ctx, [wide]), [C(0)], aggs(), group_capacity_hint=8).execute())
+        with pytest.raises(qe.QeError) as e:
+            ctx.synchronize()
+        assert e.value.name == "AggregateCapacity"
+        ctx.synchronize()  # reported once
+    finally:
+        ctx.set_flags(default_flags)
+    assert run().num_rows == 40

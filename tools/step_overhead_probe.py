@@ -3,7 +3,7 @@
 exchange (the collective replaced by a device copy into every rank's slot, so everything but the
 link latency is there) and the FINAL merge.  Prints the step time next to the kernel time.
 
-usage: step_overhead_probe.py [world] [rows_total] [steps]
+usage: step_overhead_probe.py [world] [rows_total] [steps] [deferred 0|1]
 """
 import importlib
 import os
@@ -33,7 +33,9 @@ def main():
     n = total // world
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    ctx = qe.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    work_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(work_stream)  # engine and torch on one stream: nothing else orders them in deferred mode
+    ctx = qe.Context(0, stream=work_stream.cuda_stream)
     k = torch.empty(n, dtype=torch.int64, device=dev)
     a, b, c = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
     ctx.generate(3, 43, 0, n, 0, 0, k.data_ptr())
@@ -44,7 +46,10 @@ def main():
     batches = [qe.Batch.from_torch(ctx, [k, a, b, c])]
     C = qe.ColumnExpression
     aggs = lambda col: [qe.SumExpression(C(col)), qe.CountExpression(None)]
-    xch = D.PartialExchange(torch, CopyDist(world), dev, world, 64, [torch.int64, torch.float64, torch.int64])
+    deferred = (sys.argv[4] if len(sys.argv) > 4 else "1") == "1"
+    if deferred:
+        ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_DEFERRED_GROUP_COUNT)
+    xch = D.PartialExchange(torch, CopyDist(world), dev, world, 1025 if deferred else 64, [torch.int64, torch.float64, torch.int64])
     sys.path.insert(0, ROOT)
     from bench import column_as_tensor
 
@@ -71,6 +76,7 @@ def main():
     for _ in range(3):
         out = step()
     torch.cuda.synchronize()
+    ctx.synchronize()
     marks.clear()
     ctx.profile(True)
     t0 = time.perf_counter()
@@ -80,7 +86,12 @@ def main():
     dt = (time.perf_counter() - t0) / steps
     prof = ctx.profile_read()
     kern = sum(v["ms"] for kk, v in prof.items() if kk.startswith("qe_aggregate_static")) / steps
-    print(f"world {world} rows/rank {n}: step {dt * 1e3:.3f} ms, headline kernel {kern:.3f} ms, groups {out.num_rows}")
+    ctx.synchronize()
+    cols = out.columns()
+    real = cols[2].values > 0
+    assert int(real.sum()) == 10 and int(cols[2].values[real].sum()) * 1 > 0, "merged result is wrong"
+    print("count over all ranks' copies", int(cols[2].values[real].sum()))
+    print(f"world {world} rows/rank {n} deferred={deferred}: step {dt * 1e3:.3f} ms, headline kernel {kern:.3f} ms, rows out {out.num_rows}")
     print({kk: round(v / steps * 1e3, 3) for kk, v in marks.items()}, "ms per step (host wall, includes waiting for the GPU)")
     print({kk: round(v["ms"] / steps, 4) for kk, v in prof.items()})
 
