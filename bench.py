@@ -52,6 +52,21 @@ def column_as_tensor(torch, desc, qe):
     return torch.as_tensor(DevArray(desc.values, desc.length, ts), device="cuda")
 
 
+def batch_as_block(torch, batch, n_cols):
+    """An aggregate's output in deferred mode is one device block with the columns as slices: the block as an
+    int64 tensor and each column's offset in 8-byte words, or None when the columns do not lie that way."""
+    descs = [batch.column_desc(i) for i in range(n_cols)]
+    base = descs[0].values
+    offs = [d.values - base for d in descs]
+    rows = descs[0].length
+    if any(d.validity or d.length != rows for d in descs) or offs != sorted(offs) or any(o % 8 for o in offs):
+        return None
+    if any(b - a < rows * 8 or b - a > rows * 8 + 1024 for a, b in zip(offs, offs[1:])):
+        return None
+    words = offs[-1] // 8 + rows
+    return torch.as_tensor(DevArray(base, words, "<i8"), device="cuda"), [o // 8 for o in offs], rows
+
+
 def main():
     args = parse()
     import torch
@@ -139,8 +154,13 @@ def main():
         if partitioned:
             xch = D.KeyPartitionedExchange(torch, dist, xdev, world, layout)
         else:
-            max_g = list(local_plan().execute())[0].num_rows  # rows of a partial table = slots of its group table
+            first = list(local_plan().execute())[0]
+            max_g = first.num_rows  # rows of a partial table = slots of its group table
             xch = D.PartialExchange(torch, dist, xdev, world, max_g, layout)
+            as_block = batch_as_block(torch, first, 3)
+            bxch = D.BlockExchange(torch, dist, xdev, world, as_block[0].shape[0], as_block[1], as_block[2], layout) if as_block else None
+            torch.cuda.synchronize()
+            del first, as_block
 
     def step():
         part = list(local_plan().execute())[0]
@@ -155,7 +175,8 @@ def main():
         else:
             # every rank's table in one batch, rows no rank filled are zero: COUNT(*) > 0 keeps the real ones, and the
             # FINAL aggregate merges all ranks in one launch with no trip to the host in between
-            merged = xch.exchange_merged(cols)
+            blk = batch_as_block(torch, part, 3) if bxch else None
+            merged = bxch.exchange(blk[0]) if blk else xch.exchange_merged(cols)  # the block travels as it is: nothing to pack
             scan = qe.ScanExec(ctx, [qe.Batch.from_torch(ctx, [c.to(dev) for c in merged])])
             real = qe.SelectionExec([scan], qe.GtExpression(C(2), qe.LiteralInt64Expression(0)))
             final = qe.final_plan(real, 1, aggs(1), group_capacity_hint=hint)

@@ -773,10 +773,12 @@ struct AggState {
   std::vector<Utf8KeySource> key_sources;
   int64_t row_base = 0;
   int deferred_finishes = 0;
+  BufferPtr deferred_block;  // output block of the deferred mode, cleared by the table's init launch
 
   // Fresh table for about `hint` groups.
   void start(int64_t hint) {
     deferred_finishes = 0;
+    deferred_block.reset();
     cap = 1024;
     while (cap < (uint64_t)hint * 2) cap <<= 1;
     if (cap > (1ull << 30)) fail(QE_ERR_AGG_CAPACITY, "group table would exceed 2^30 slots");
@@ -830,8 +832,16 @@ struct AggState {
       table.ctrl = table.nn + (size_t)na * table.stride;
       std::vector<VmAcc> va;
       for (auto &d : spec.accs) va.push_back(d.acc);
+      void *zero = nullptr;
+      size_t zero_bytes = 0;
+      if (deferred_wanted()) {
+        std::vector<size_t> at;
+        zero_bytes = deferred_layout(at);
+        deferred_block = device_buffer(ctx, zero_bytes + 256);
+        zero = deferred_block->ptr;
+      }
       ctx->prof_begin("qe_table_init_kernel");
-      QE_HIP(launch_table_init(table, va.data(), na, ctx->stream));
+      QE_HIP(launch_table_init(table, va.data(), na, ctx->stream, zero, zero_bytes));
       ctx->prof_end();
       have_table = true;
     } else {
@@ -871,9 +881,9 @@ struct AggState {
   // The output without a word from the device: one row per table slot, the rows past the group count
   // all zero (values and validity), every column a slice of one zeroed block.  The control words
   // travel to a pinned slot that the next synchronise examines.
-  bool finish_deferred(Batch &result) {
+  // Layout of the deferred output block: per output column the values slice, then (nullable outputs) the bitmap.
+  size_t deferred_layout(std::vector<size_t> &at) const {
     const int64_t capacity = (int64_t)table.cap + 1;
-    std::vector<size_t> at;
     size_t total = 0;
     for (auto &f : spec.outs) {
       at.push_back(total);
@@ -881,8 +891,22 @@ struct AggState {
       at.push_back(total);
       if (f.null_mode != NULL_NEVER) total += (bitmap_bytes(capacity) + 255) & ~(size_t)255;
     }
-    BufferPtr block = device_buffer(ctx, total + 256);
-    QE_HIP(hipMemsetAsync(block->ptr, 0, total, ctx->stream));
+    return total;
+  }
+  bool deferred_wanted() const {
+    return table.cap + 1 <= (1u << 16) && (ctx->flags & QE_FLAG_DEFERRED_GROUP_COUNT) && spec.utf8_key_out < 0;
+  }
+
+  bool finish_deferred(Batch &result) {
+    const int64_t capacity = (int64_t)table.cap + 1;
+    std::vector<size_t> at;
+    const size_t total = deferred_layout(at);
+    BufferPtr block = deferred_block;  // cleared together with the table, if this is the first result taken
+    deferred_block.reset();
+    if (!block) {
+      block = device_buffer(ctx, total + 256);
+      QE_HIP(hipMemsetAsync(block->ptr, 0, total, ctx->stream));
+    }
     FinalizeArgs fa{};
     fa.table = table;
     fa.n_outs = (int)spec.outs.size();
@@ -925,7 +949,7 @@ struct AggState {
     // before the group count is known, so that one trip to the host serves both.  Large tables
     // read the count first and allocate exactly.
     const bool eager = table.cap + 1 <= (1u << 16);
-    if (eager && (ctx->flags & QE_FLAG_DEFERRED_GROUP_COUNT) && spec.utf8_key_out < 0) return finish_deferred(result);
+    if (deferred_wanted()) return finish_deferred(result);
     unsigned long long n_groups = 0, overflow = 0;
     if (!eager) {
       QE_HIP(hipMemcpyAsync(ctx->host_counters + 16, table.ctrl, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));

@@ -44,7 +44,8 @@ hipError_t launch_aggregate_partitioned(const PartArgs &args, const DeviceInfo &
 int aggregate_grid(const AggArgs &args, const DeviceInfo &dev);
 
 // Fill a fresh global group table with the empty key / accumulator identities.
-hipError_t launch_table_init(const AggTable &table, const VmAcc *accs, int n_accs, hipStream_t stream);
+// `zero` (optional, 8-byte aligned, a multiple of 8 bytes): a buffer cleared by the same launch.
+hipError_t launch_table_init(const AggTable &table, const VmAcc *accs, int n_accs, hipStream_t stream, void *zero = nullptr, size_t zero_bytes = 0);
 // Compact occupied slots into output columns.
 hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream);
 

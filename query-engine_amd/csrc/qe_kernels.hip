@@ -413,7 +413,9 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
 }
 
 // ------------------------------------------------------ table init/finalize
-__global__ void qe_table_init_kernel(AggTable T, uint64_t packed_lo, uint64_t packed_hi, int n_accs) {
+__global__ void qe_table_init_kernel(AggTable T, uint64_t packed_lo, uint64_t packed_hi, int n_accs, unsigned long long *zero, uint64_t zero_words) {
+  // (an output block to clear rides along: one launch instead of two in front of a small aggregate)
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < zero_words; i += (uint64_t)gridDim.x * blockDim.x) zero[i] = 0;
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < T.stride;
        i += (uint64_t)gridDim.x * blockDim.x) {
     T.keys[i] = AGG_EMPTY_KEY;
@@ -922,12 +924,13 @@ hipError_t launch_aggregate_partitioned(const PartArgs &args, const DeviceInfo &
   return hipGetLastError();
 }
 
-hipError_t launch_table_init(const AggTable &table, const VmAcc *accs, int n_accs, hipStream_t stream) {
+hipError_t launch_table_init(const AggTable &table, const VmAcc *accs, int n_accs, hipStream_t stream, void *zero, size_t zero_bytes) {
   static_assert(VM_MAX_ACCS <= 16, "two packed words hold 16 accumulator ops");
   uint64_t packed[2] = {0, 0};
   for (int i = 0; i < n_accs && i < VM_MAX_ACCS; ++i) packed[i >> 3] |= (uint64_t)accs[i].op << (8 * (i & 7));
   int grid = grid_for((int64_t)table.stride, 256, 4096);
-  hipLaunchKernelGGL(qe_table_init_kernel, dim3(grid), dim3(256), 0, stream, table, packed[0], packed[1], n_accs);
+  hipLaunchKernelGGL(qe_table_init_kernel, dim3(grid), dim3(256), 0, stream, table, packed[0], packed[1], n_accs, (unsigned long long *)zero,
+                     (uint64_t)(zero_bytes / 8));
   return hipGetLastError();
 }
 

@@ -161,3 +161,22 @@ def test_exchange_rejects_oversized_table():
     k, v = x.exchange_merged([torch.arange(2) + 7, torch.full((2,), 2.0, dtype=torch.float64)])
     assert k.tolist() == [7, 8, 0, 0] and v.tolist() == [2.0, 2.0, 0.0, 0.0]
     assert d.shard_range(10, 0, 3) == (0, 3) and d.shard_range(10, 2, 3) == (6, 10)
+
+
+def test_block_exchange_layout():
+    """BlockExchange: blocks gathered as they are, one gather kernel to contiguous columns."""
+    import torch
+    d = importlib.import_module("query-engine_amd.distributed")
+
+    class TwoRanks:  # rank 1's block is rank 0's plus 100
+        def all_gather_into_tensor(self, out, inp):
+            out.view(2, -1)[0].copy_(inp)
+            out.view(2, -1)[1].copy_(inp + 100)
+    rows, offs, words = 3, [0, 4, 8], 11  # slices with a word of padding between them
+    block = torch.arange(words, dtype=torch.int64)
+    x = d.BlockExchange(torch, TwoRanks(), "cpu", 2, words, offs, rows, [torch.int64, torch.int64, torch.int64])
+    k, s, c = x.exchange(block)
+    assert k.tolist() == [0, 1, 2, 100, 101, 102] and s.tolist() == [4, 5, 6, 104, 105, 106] and c.tolist() == [8, 9, 10, 108, 109, 110]
+    assert all(t.is_contiguous() for t in (k, s, c))
+    with pytest.raises(ValueError):
+        x.exchange(block[:5])

@@ -51,7 +51,8 @@ def main():
         ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_DEFERRED_GROUP_COUNT)
     xch = D.PartialExchange(torch, CopyDist(world), dev, world, 1025 if deferred else 64, [torch.int64, torch.float64, torch.int64])
     sys.path.insert(0, ROOT)
-    from bench import column_as_tensor
+    from bench import batch_as_block, column_as_tensor
+    bx = {}
 
     marks = {}
 
@@ -62,8 +63,14 @@ def main():
         proj = qe.ProjectionExec([sel], [C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
         part = list(qe.AggregateExec([proj], [C(0)], aggs(1), mode=qe.AGG_MODE_PARTIAL, group_capacity_hint=64).execute())[0]
         t1 = time.perf_counter()
-        cols = [column_as_tensor(torch, part.column_desc(i), qe) for i in range(3)]
-        merged = xch.exchange_merged(cols)
+        blk = batch_as_block(torch, part, 3) if deferred else None
+        if blk:
+            if "x" not in bx:
+                bx["x"] = D.BlockExchange(torch, CopyDist(world), dev, world, blk[0].shape[0], blk[1], blk[2], [torch.int64, torch.float64, torch.int64])
+            merged = bx["x"].exchange(blk[0])
+        else:
+            cols = [column_as_tensor(torch, part.column_desc(i), qe) for i in range(3)]
+            merged = xch.exchange_merged(cols)
         t2 = time.perf_counter()
         scan = qe.ScanExec(ctx, [qe.Batch.from_torch(ctx, merged)])
         real = qe.SelectionExec([scan], qe.GtExpression(C(2), qe.LiteralInt64Expression(0)))
