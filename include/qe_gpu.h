@@ -311,7 +311,9 @@ qe_status qe_generate_column(qe_context *ctx, int32_t kind, uint64_t seed, int64
 
 /* Device timing of the kernels the last qe_iter_next / qe_expr_evaluate call
  * launched on this context: name, launches and total milliseconds measured
- * with HIP events on the context's stream (enabled by qe_context_profile). */
+ * with HIP events on the context's stream (enabled by qe_context_profile:
+ * 1 = every launch, 2 = only the main kernels of launches over at least 2^20
+ * rows, leaving the small helper launches of a step free of event records). */
 qe_status qe_context_profile(qe_context *ctx, int32_t enable);
 qe_status qe_context_profile_read(qe_context *ctx, char *buf, int64_t buf_len, int64_t *needed);
 

@@ -189,7 +189,8 @@ class Context:
         _check(lib.qe_context_synchronize(self._h))
 
     def profile(self, enable=True):
-        _check(lib.qe_context_profile(self._h, 1 if enable else 0))
+        """True / 1: time every launch; 2: only the main kernels of large launches; False: off."""
+        _check(lib.qe_context_profile(self._h, int(enable)))
 
     def profile_read(self):
         import json

@@ -62,8 +62,9 @@ void Context::release(void *p, size_t actual) {
   pool_bytes += actual;
 }
 
-void Context::prof_begin(const char *name) {
-  if (!profiling) return;
+void Context::prof_begin(const char *name, int64_t rows) {
+  prof_open = profiling && (profile_min_rows == 0 || rows >= profile_min_rows);  // small helpers (rows unknown = -1) are skipped when a floor is set
+  if (!prof_open) return;
   LaunchRec r;
   r.name = name;
   QE_HIP(hipEventCreate(&r.start));
@@ -72,7 +73,8 @@ void Context::prof_begin(const char *name) {
   launches.push_back(r);
 }
 void Context::prof_end(const char *actual_name) {
-  if (!profiling || launches.empty()) return;
+  if (!prof_open || launches.empty()) return;
+  prof_open = false;
   if (actual_name) launches.back().name = actual_name;
   QE_HIP(hipEventRecord(launches.back().stop, stream));
 }

@@ -53,6 +53,8 @@ struct Context : std::enable_shared_from_this<Context> {
   unsigned long long *host_counters = nullptr;  // pinned mirror
   // profiling
   bool profiling = false;
+  int64_t profile_min_rows = 0;  // > 0: only launches over at least this many rows are timed
+  bool prof_open = false;        // the launch between prof_begin and prof_end is being timed
   struct LaunchRec {
     const char *name;
     hipEvent_t start, stop;
@@ -63,7 +65,7 @@ struct Context : std::enable_shared_from_this<Context> {
   void release(void *p, size_t actual);
   void bind() const;
   void sync() const;
-  void prof_begin(const char *name);
+  void prof_begin(const char *name, int64_t rows = -1);  // rows: what the launch covers, when known
   void prof_end(const char *actual_name = nullptr);  // the kernel variant the launcher picked
   ~Context();
 };

@@ -341,7 +341,7 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
         out.cols[i] = c;
       });
       const char *kname = "qe_project_kernel";
-      ctx->prof_begin(kname);
+      ctx->prof_begin(kname, n);
       QE_HIP(launch_project(args, ctx->dev, ctx->stream, &kname));
       ctx->prof_end(kname);
       if (!comp.keepalive.empty()) ctx->sync();
@@ -387,7 +387,7 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
     args.scratch = scratch;
     QE_HIP(launch_filter_reset(scratch, n, ctx->stream));
     const char *kname = "qe_filter_kernel";
-    ctx->prof_begin(kname);
+    ctx->prof_begin(kname, n);
     QE_HIP(launch_filter(args, ctx->dev, ctx->stream, &kname));
     ctx->prof_end(kname);
     if (first) {
@@ -871,7 +871,7 @@ struct AggState {
     args.lds_limit = args.lds_cap - args.lds_cap / 4;
     SpillPlan sp = plan_spill(ctx, bspec, args, cap_hint);
     const char *kname = "qe_aggregate_kernel";
-    ctx->prof_begin(kname);
+    ctx->prof_begin(kname, in.rows);
     QE_HIP(launch_aggregate(args, ctx->dev, ctx->stream, &kname));
     ctx->prof_end(kname);
     if (sp.on) aggregate_spilled(ctx, sp, args, cap_hint);
@@ -2002,6 +2002,7 @@ qe_status qe_context_profile(qe_context *ctx, int32_t enable) {
   return guarded([&] {
     QE_REQUIRE(ctx, "ctx is null");
     ctx->c.profiling = enable != 0;
+    ctx->c.profile_min_rows = enable == 2 ? (int64_t)1 << 20 : 0;
   });
 }
 

@@ -85,7 +85,7 @@ def main():
     torch.cuda.synchronize()
     ctx.synchronize()
     marks.clear()
-    ctx.profile(True)
+    ctx.profile(int(os.environ.get("PROBE_PROFILE", "2")))
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
