@@ -80,8 +80,14 @@ def main():
     backend = os.environ.get("QE_BENCH_BACKEND", "nccl")
     if backend == "gloo":
         local_rank = local_rank % torch.cuda.device_count()
-    if world > 1:
+    # QE_BENCH_FORCE_DIST=1 runs the multi-rank code path (PARTIAL aggregate, exchange, FINAL merge) with whatever
+    # world size the launcher gave, 1 included: a one-GPU box can then exercise the real RCCL calls.
+    multi = world > 1 or os.environ.get("QE_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -126,7 +132,7 @@ def main():
 
     batches = batches_of([k, a, b, c], n)
     C = qe.ColumnExpression
-    mode = qe.AGG_MODE_PARTIAL if world > 1 else qe.AGG_MODE_SINGLE
+    mode = qe.AGG_MODE_PARTIAL if multi else qe.AGG_MODE_SINGLE
     aggs = lambda col: [qe.SumExpression(C(col)), qe.CountExpression(None)]
     hint = max(64, 2 * args.groups)
 
@@ -147,7 +153,7 @@ def main():
     default_flags = qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP
     if deferred:
         ctx.set_flags(default_flags | qe.FLAG_DEFERRED_GROUP_COUNT)
-    if world > 1:
+    if multi:
         from importlib import import_module
         D = import_module("query-engine_amd.distributed")
         layout = [torch.int64, torch.float64, torch.int64]
@@ -164,7 +170,7 @@ def main():
 
     def step():
         part = list(local_plan().execute())[0]
-        if world == 1:
+        if not multi:
             return part
         cols = [column_as_tensor(torch, part.column_desc(i), qe) for i in range(3)]
         # the only collective of the plan: the exchange of the partial tables over xGMI
@@ -183,7 +189,7 @@ def main():
         return list(final.execute())[0]
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()  # also reports a deferred aggregate that overflowed its table
@@ -201,7 +207,7 @@ def main():
     prof = ctx.profile_read()
     ctx.profile(False)
     ctx.set_flags(default_flags)
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -237,7 +243,7 @@ def main():
                    "host_sync": "none inside a step (deferred group count); barrier + device synchronise around the timed steps" if deferred
                    else "per aggregate",
                    "merge": (f"{'rccl' if backend == 'nccl' else backend} " + ("all_to_all by key owner" if partitioned else "all_gather") +
-                             " + FINAL aggregate") if world > 1 else "none"},
+                             " + FINAL aggregate") if multi else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kname,
                      "avg_launch_ms": avg_ms, "rows_per_launch": rows_per_launch},
@@ -251,7 +257,7 @@ def main():
         col.values = np.asarray(col.values)[real]
     groups_here = torch.tensor([int(real.sum()), 0], dtype=torch.int64, device=xdev)
     groups_here[1] = int(cols[2].values.sum())
-    if world > 1 and partitioned:
+    if multi and partitioned:
         dist.all_reduce(groups_here)  # every rank holds a share of the groups
     if rank == 0:
         order = np.argsort(cols[0].values)
@@ -265,7 +271,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.cpu_rows, seed)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
