@@ -73,14 +73,15 @@ class PartialExchange:
 class BlockExchange:
     """The exchange for partial tables that already lie in one device block (an aggregate run with
     deferred group count returns all its columns as slices of one allocation, one row per table slot,
-    unused rows zero): the block itself is the all-gather payload, so nothing is packed, and one
-    gather kernel turns the received blocks into a single table of world x rows rows whose columns
+    unused rows zero): the block is the all-gather payload as it is (one copy into the send buffer
+    instead of one per column), and one gather kernel turns the received blocks into a single table of world x rows rows whose columns
     are contiguous.  Column i of the block starts `offsets[i]` 8-byte words into it.  As with
     PartialExchange.exchange_merged, COUNT(*) > 0 tells real rows from padding."""
 
     def __init__(self, torch, dist, device, world, words, offsets, rows, dtypes):
         self.torch, self.dist, self.device, self.world = torch, dist, device, world
         self.words, self.rows, self.dtypes = words, rows, list(dtypes)
+        self.send = torch.zeros(words, dtype=torch.int64, device=device)
         self.recv = torch.zeros(world * words, dtype=torch.int64, device=device)
         r = torch.arange(world, dtype=torch.int64).view(1, world, 1) * words
         j = torch.arange(rows, dtype=torch.int64).view(1, 1, rows)
@@ -91,8 +92,10 @@ class BlockExchange:
         """block: int64 tensor over this rank's partial-table block (`words` long)."""
         if block.shape[0] != self.words:
             raise ValueError("block size differs from the exchange layout")
-        send = block if block.device == self.recv.device else block.to(self.recv.device)
-        self.dist.all_gather_into_tensor(self.recv, send)
+        # one copy into a buffer the collective library has seen before: the block is engine memory, a different
+        # allocation every step
+        self.send.copy_(block)
+        self.dist.all_gather_into_tensor(self.recv, self.send)
         merged = self.recv[self.index].view(len(self.dtypes), self.world * self.rows)
         return [merged[i].view(self.torch.float64) if d == self.torch.float64 else merged[i] for i, d in enumerate(self.dtypes)]
 
