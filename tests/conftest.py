@@ -17,6 +17,12 @@ def pytest_configure(config):
 def qe():
     """The product package (ctypes binding over libqe_gpu.so)."""
     import importlib
+    try:
+        # torch brings a HIP runtime of its own; loaded after the engine's, a process ends up with two and the
+        # second to initialise finds no device.  Loaded first, both share torch's.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     return importlib.import_module("query-engine_amd")
 
 

@@ -1,0 +1,157 @@
+"""The configurations at their full sizes (100 M / 500 M / 1 B rows, and one batch past 2^31 rows),
+checked through properties that do not need the oracle to chew through them: counts against
+torch reductions over the same device columns, stable compaction as "the output of a prefix is a
+prefix of the output" (that prefix checked bit for bit against the oracle), the aggregate of the
+whole against the merge of the aggregates of its parts, sums within 1e-12 of the magnitude summed.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-12  # float64 SUM / AVG tolerance, relative to the sum of magnitudes
+
+
+@pytest.fixture(scope="module")
+def torch_ctx(qe):
+    """Engine and torch on one stream, so that torch reductions see what the engine wrote and vice versa."""
+    import torch
+    torch.cuda.set_device(0)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    c = qe.Context(0, stream=stream.cuda_stream)
+    yield torch, c
+    torch.cuda.synchronize()
+    c.close()
+    torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def table(torch, ctx, n, key_kind=3, key_lo=0, key_hi=0):
+    dev = torch.device("cuda", 0)
+    k = torch.empty(n, dtype=torch.int64, device=dev)
+    a, b, c = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
+    ctx.generate(key_kind, 43, 0, n, key_lo, key_hi, k.data_ptr())
+    ctx.generate(0, 44, 0, n, -1.0, 1.0, a.data_ptr())
+    ctx.generate(0, 45, 0, n, -1.0, 1.0, b.data_ptr())
+    ctx.generate(0, 46, 0, n, 0.0, 1.0, c.data_ptr())
+    ctx.synchronize()
+    return k, a, b, c
+
+
+def by_key(cols):
+    order = np.argsort(np.asarray(cols[0].values))
+    return [np.asarray(c.values)[order] for c in cols]
+
+
+def test_c2_filter_project_100m(qe, torch_ctx):
+    torch, ctx = torch_ctx
+    n = 100_000_000
+    _, a, b, c = table(torch, ctx, n)
+    C = qe.ColumnExpression
+    pred = lambda m: m.GtExpression(m.ColumnExpression(2), m.LiteralFloatExpression(0.5))
+    expr = lambda m: m.AddExpression(m.ColumnExpression(0), m.MulExpression(m.ColumnExpression(1), m.ColumnExpression(2)))
+    batch = qe.Batch.from_torch(ctx, [a, b, c])
+    out = list(qe.ProjectionExec([qe.SelectionExec([qe.ScanExec(ctx, [batch])], pred(qe))], [expr(qe)]).execute())[0]
+    keep = c > 0.5
+    assert out.num_rows == int(keep.sum())
+    desc = out.column_desc(0)
+    from bench import DevArray
+    got = torch.as_tensor(DevArray(desc.values, desc.length, "<f8"), device="cuda")
+    # the whole output, bit for bit: torch evaluates a + b*c with two roundings as well
+    want = (a + b * c)[keep]
+    assert torch.equal(got.view(torch.int64), want.view(torch.int64))
+    # and the oracle on a prefix: stable compaction makes its output a prefix of the output
+    m = 1_000_000
+    chunk = orc.Chunk([orc.Array(orc.FLOAT64, t[:m].cpu().numpy()) for t in (a, b, c)])
+    ref = list(orc.ProjectionExec([orc.SelectionExec([orc.ScanExec([chunk])], pred(orc))], [expr(orc)]).execute())[0].arrays[0].values
+    assert np.array_equal(got[:len(ref)].cpu().numpy().view(np.uint64), ref.view(np.uint64))
+
+
+def test_c3_groupby_500m(qe, torch_ctx):
+    torch, ctx = torch_ctx
+    n = 500_000_000
+    k, _, _, c = table(torch, ctx, n)
+    C = qe.ColumnExpression
+    step = 1 << 28
+    batches = [qe.Batch.from_torch(ctx, [k[s:s + step], c[s:s + step]]) for s in range(0, n, step)]
+    out = list(qe.AggregateExec([qe.ScanExec(ctx, batches)], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None), qe.MinExpression(C(1)),
+                                                                        qe.MaxExpression(C(1))], group_capacity_hint=64).execute())[0]
+    keys, sums, counts, mins, maxs = by_key(out.columns())
+    want_counts = torch.bincount(k).cpu().numpy()
+    assert np.array_equal(keys, np.nonzero(want_counts)[0]) and np.array_equal(counts, want_counts[want_counts > 0])
+    assert counts.sum() == n
+    for key, total, lo, hi in zip(keys, sums, mins, maxs):
+        mine = k == int(key)
+        want = float(torch.where(mine, c, torch.zeros((), dtype=torch.float64, device="cuda")).sum())  # torch.sum reduces as a tree
+        assert abs(total - want) <= REL * want  # values are positive: the sum of magnitudes is the sum
+        sel = c[mine]
+        assert lo == float(sel.min()) and hi == float(sel.max())
+
+
+def test_c5_whole_equals_merge_of_parts_1b(qe, torch_ctx):
+    torch, ctx = torch_ctx
+    n = 1_000_000_000
+    k, a, b, c = table(torch, ctx, n)
+    C = qe.ColumnExpression
+    aggs = lambda: [qe.SumExpression(C(1)), qe.CountExpression(None), qe.AvgExpression(C(1))]
+
+    def plan(lo, hi, mode):
+        step = 1 << 28
+        batches = [qe.Batch.from_torch(ctx, [t[s:min(hi, s + step)] for t in (k, a, b, c)]) for s in range(lo, hi, step)]
+        sel = qe.SelectionExec([qe.ScanExec(ctx, batches)], qe.GtExpression(C(3), qe.LiteralFloatExpression(0.5)))
+        proj = qe.ProjectionExec([sel], [C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
+        return qe.AggregateExec([proj], [C(0)], aggs(), mode=mode, group_capacity_hint=64)
+    whole = by_key(list(plan(0, n, qe.AGG_MODE_SINGLE).execute())[0].columns())
+    cuts = [0, 123_456_789, 600_000_001, n]  # ragged shards
+    parts = []
+    for lo, hi in zip(cuts, cuts[1:]):
+        parts += list(plan(lo, hi, qe.AGG_MODE_PARTIAL).execute())
+    merged = by_key(list(qe.final_plan(qe.ScanExec(ctx, parts), 1, aggs()).execute())[0].columns())
+    assert np.array_equal(whole[0], merged[0]) and np.array_equal(whole[2], merged[2])
+    keep = c > 0.5
+    assert whole[2].sum() == int(keep.sum())
+    v = a + b * c
+    zero = torch.zeros((), dtype=torch.float64, device="cuda")
+    for i, key in enumerate(whole[0]):
+        mine = keep & (k == int(key))
+        ref = float(torch.where(mine, v, zero).sum())  # torch.sum reduces as a tree: accurate far below the tolerance
+        mag = float(torch.where(mine, v.abs(), zero).sum())
+        assert abs(whole[1][i] - ref) <= REL * mag and abs(merged[1][i] - ref) <= REL * mag
+        assert abs(whole[3][i] - ref / whole[2][i]) <= REL * mag / whole[2][i]
+
+
+def test_one_batch_past_2_to_31_rows(qe, torch_ctx):
+    """2.4 G rows in a single batch: row positions and counts are 64-bit all the way."""
+    torch, ctx = torch_ctx
+    n = 2_400_000_000
+    half = 1_200_000_000
+    dev = torch.device("cuda", 0)
+    k = torch.empty(n, dtype=torch.int64, device=dev)
+    c = torch.empty(n, dtype=torch.float64, device=dev)
+    ctx.generate(3, 43, 0, n, 0, 0, k.data_ptr())
+    ctx.generate(0, 46, 0, n, 0.0, 1.0, c.data_ptr())
+    ctx.synchronize()
+    C = qe.ColumnExpression
+
+    def count_by_key(lo, hi):
+        b = qe.Batch.from_torch(ctx, [k[lo:hi], c[lo:hi]])
+        out = list(qe.AggregateExec([qe.ScanExec(ctx, [b])], [C(0)], [qe.CountExpression(None), qe.MaxExpression(C(1))], group_capacity_hint=64).execute())[0]
+        return by_key(out.columns())
+    whole, first, second = count_by_key(0, n), count_by_key(0, half), count_by_key(half, n)
+    assert whole[1].sum() == n
+    assert np.array_equal(whole[0], first[0]) and np.array_equal(whole[1], first[1] + second[1])
+    assert np.array_equal(whole[2], np.maximum(first[2], second[2]))
+
+    # stable compaction across the 2^31 boundary: the output of the whole is the outputs of the halves, in order
+    def select(lo, hi):
+        b = qe.Batch.from_torch(ctx, [k[lo:hi], c[lo:hi]])
+        out = list(qe.SelectionExec([qe.ScanExec(ctx, [b])], qe.GtExpression(C(1), qe.LiteralFloatExpression(0.999))).execute())[0]
+        cols = out.columns()
+        return np.asarray(cols[0].values), np.asarray(cols[1].values)
+    wk, wc = select(0, n)
+    fk, fc = select(0, half)
+    sk, sc = select(half, n)
+    assert len(wc) == len(fc) + len(sc) == int((c > 0.999).sum())
+    assert np.array_equal(wk, np.concatenate([fk, sk])) and np.array_equal(wc.view(np.uint64), np.concatenate([fc, sc]).view(np.uint64))
