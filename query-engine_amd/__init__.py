@@ -14,6 +14,12 @@ Names follow the reference (paths relative to /root/reference/query-engine/src):
 Every call goes through ctypes into the HIP library; there is no CPU fallback:
 importing this package without the built library raises ImportError and creating
 a Context without a gfx950 device raises QeError(DeviceError).
+
+With PyTorch in the same process, import torch first: its wheel carries a HIP
+runtime of its own, and of two runtimes in one process the second to initialise
+finds no device.  Loaded after torch, this library binds to torch's.  Pass
+`torch.cuda.Stream().cuda_stream` (not the default stream, whose handle is 0 =
+"make your own") to Context to share one stream with torch.
 """
 import ctypes as C
 import os
