@@ -27,7 +27,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqe_gpu.so")
+LIB_PATH = os.environ.get("QE_GPU_LIBRARY") or os.path.join(_HERE, "libqe_gpu.so")  # the override serves A/B timing of two builds
 
 # ---- constants (include/qe_gpu.h)
 QE_OK, QE_END = 0, 1

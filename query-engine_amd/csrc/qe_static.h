@@ -442,9 +442,72 @@ __device__ __forceinline__ void hot_fold(HotCache<Spec::n_accs> &C, const Slot &
   }
 }
 
+// Dense-key bins.  When the packed key of a row is a small number (a boolean, a category code, a
+// passenger count) nothing has to be looked up: the key addresses a bin directly.  Every lane has
+// bins of its own - rows[key][lane], acc[a][key][lane], shared by the workgroup's waves - so that
+// LDS atomics on them never meet on an address within a wave and never conflict on a bank
+// (consecutive lanes, consecutive words), whatever the key distribution: a row costs one LDS add
+// for the count and one LDS operation per accumulator, no hashing, no probing, no compare chains.
+// Rows with other keys take the hot-key / hash-table path.  The host switches the bins on (a byte
+// offset into dynamic LDS) for aggregates with few groups and inputs that cannot be null.
+struct DenseBins {
+  uint32_t *rows;
+  unsigned long long *acc;
+  bool on;
+};
+
+template <class Spec>
+__device__ __forceinline__ void dense_clear(const DenseBins &D) {
+  if (!D.on) return;
+  for (uint32_t i = threadIdx.x; i < DENSE_KEYS * 64u; i += blockDim.x) {
+    D.rows[i] = 0;
+#pragma unroll
+    for (int a = 0; a < Spec::n_accs; ++a) D.acc[(uint32_t)a * DENSE_KEYS * 64u + i] = acc_identity(Spec::acc_op[a]);
+  }
+}
+
+template <class Spec, int ACC>
+__device__ __forceinline__ void dense_fold(const DenseBins &D, const Slot &in, const uint64_t (&key)[VM_R], uint32_t dm, uint32_t lane) {
+  constexpr uint32_t op = Spec::acc_op[ACC], in_type = Spec::acc_type[ACC];
+  const uint32_t m = dm & in.valid;
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    if ((m >> j) & 1u) {
+      uint64_t x = in.v[j];
+      bool take = true;
+      if (op == ACC_MIN || op == ACC_MAX) {
+        if (in_type == VT_F64 && u2d(x) != u2d(x)) take = false;  // NaN is ignored by min / max
+        x = ord_image(x, in_type);
+      } else if (op == ACC_COUNT) {
+        x = 1;
+      }
+      if (take) acc_apply(&D.acc[((uint32_t)ACC * DENSE_KEYS + (uint32_t)key[j]) * 64u + lane], op, x);
+    }
+  }
+}
+
+// Wave `wave` of the workgroup adds the bins of its share of the keys to the global table.
+template <class Spec>
+__device__ __forceinline__ void dense_flush(const DenseBins &D, const AggTable &T, uint32_t wave, uint32_t lane) {
+  if (!D.on) return;
+  for (uint32_t key = wave; key < DENSE_KEYS; key += VM_BLOCK_WAVES) {
+    const unsigned long long rows = wave_sum_u64(D.rows[key * 64u + lane]);
+    if (rows == 0) continue;
+    long long g = -1;
+    if (lane == 0) g = global_find_or_claim(T, key, mix64(key));  // full table: flagged for the host
+    if (lane == 0 && g >= 0) atomicAdd(&T.rowcnt[g], rows);
+#pragma unroll
+    for (int a = 0; a < Spec::n_accs; ++a) {
+      const uint32_t op = Spec::acc_op[a];
+      const uint64_t part = wave_reduce_acc(op, D.acc[((uint32_t)a * DENSE_KEYS + key) * 64u + lane]);
+      if (lane == 0 && g >= 0 && (part != acc_identity(op) || op == ACC_SUM_F64)) acc_apply(&T.acc[(uint64_t)a * T.stride + g], op, part);
+    }
+  }
+}
+
 template <class Spec, int T>
-__device__ __forceinline__ void agg_tasks_static(const AggArgs &A, const LdsTable &L, RowCtx &c, const ColCache &K, AggRows &G,
-                                                 HotCache<Spec::n_accs> &C, uint32_t (&hm)[HOT_KEYS], SpillState &sp, uint32_t lane) {
+__device__ __forceinline__ void agg_tasks_static(const AggArgs &A, const LdsTable &L, const DenseBins &D, uint32_t &dm, RowCtx &c, const ColCache &K,
+                                                 AggRows &G, HotCache<Spec::n_accs> &C, uint32_t (&hm)[HOT_KEYS], SpillState &sp, uint32_t lane) {
   if constexpr (T < Spec::n_tasks) {
     constexpr uint32_t role = Spec::task_role[T], idx = Spec::task_idx[T];
     Slot S[VM_MAX_DEPTH];
@@ -462,18 +525,34 @@ __device__ __forceinline__ void agg_tasks_static(const AggArgs &A, const LdsTabl
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) G.key[j] |= (S[0].v[j] & fmask) << sh;
     } else if constexpr (role == ROLE_LOOKUP) {
-      const uint32_t rest = hot_match<Spec>(C, A.table, G.key, c.active, lane, hm);
+      // The bins take the rows with small keys (an LDS add per row instead of the hot keys' compare-and-select
+      // chains); the hot keys in registers and then the hash tables see the rest.
+      uint32_t rest = c.active;
+      dm = 0;
+      if (D.on) {
 #pragma unroll
-      for (int h = 0; h < HOT_KEYS; ++h) C.rows[h] += (uint32_t)__popc(hm[h]);
+        for (int j = 0; j < VM_R; ++j)
+          if (((rest >> j) & 1u) && G.key[j] < DENSE_KEYS) {
+            dm |= 1u << j;
+            atomicAdd(&D.rows[(uint32_t)G.key[j] * 64u + lane], 1u);
+          }
+        rest &= ~dm;
+      }
+      if (__ballot(rest != 0) != 0) {
+        rest = hot_match<Spec>(C, A.table, G.key, rest, lane, hm);
+#pragma unroll
+        for (int h = 0; h < HOT_KEYS; ++h) C.rows[h] += (uint32_t)__popc(hm[h]);
+      }
       // rows of other keys: LDS / global table (no dominant-key search: the hot keys took those)
       agg_lookup<false>(L, A.table, rest, lane, G, sp);
     } else {
-      hot_fold<Spec, (int)idx>(C, S[0], hm);
+      if (__ballot((hm[0] | hm[1]) != 0) != 0) hot_fold<Spec, (int)idx>(C, S[0], hm);
+      if (dm != 0) dense_fold<Spec, (int)idx>(D, S[0], G.key, dm, lane);
       if (G.spill_mb != 0 && A.spill_col[idx] != 0xffu) spill_values(sp, A.spill_col[idx], S[0], G);
       if (__ballot(G.rem != 0) != 0)
         agg_fold(L, A.table, idx, Spec::acc_op[idx], Spec::acc_type[idx], Spec::acc_track[idx] != 0, S[0], G, lane);
     }
-    agg_tasks_static<Spec, T + 1>(A, L, c, K, G, C, hm, sp, lane);
+    agg_tasks_static<Spec, T + 1>(A, L, D, dm, c, K, G, C, hm, sp, lane);
   }
 }
 
@@ -485,7 +564,12 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_aggregate_static(const
   const int64_t n = A.n_rows;
   LdsTable L;
   agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, Spec::n_accs);
-  agg_lds_clear(L, A.accs, Spec::n_accs);
+  DenseBins D;
+  D.on = A.dense_off != 0;
+  D.rows = (uint32_t *)((char *)lds_raw + A.dense_off);
+  D.acc = (unsigned long long *)(D.rows + DENSE_KEYS * 64u);
+  dense_clear<Spec>(D);
+  agg_lds_clear(L, A.accs, Spec::n_accs);  // ends with a barrier
 
   HotCache<Spec::n_accs> C;
   C.valid = 0;
@@ -515,9 +599,12 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_aggregate_static(const
     G.spill_mb = 0;
     G.spill_pos = 0;
     uint32_t hm[HOT_KEYS] = {0, 0};
-    agg_tasks_static<Spec, 0>(A, L, c, K, G, C, hm, sp, lane);
+    uint32_t dm = 0;
+    agg_tasks_static<Spec, 0>(A, L, D, dm, c, K, G, C, hm, sp, lane);
   }
   spill_end(A.spill, sp, wave, lane);
+  __syncthreads();  // every wave's bin updates are in
+  dense_flush<Spec>(D, A.table, wave, lane);
   hot_flush<Spec, 0>(C, A.table, lane, (C.valid & 1u) != 0);
   hot_flush<Spec, 1>(C, A.table, lane, (C.valid & 2u) != 0);
   agg_flush(L, A.table, A.accs, Spec::n_accs);

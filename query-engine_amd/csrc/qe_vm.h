@@ -171,6 +171,11 @@ struct AggTable {
 
 constexpr unsigned long long AGG_EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
 
+// Dense-key bins of the specialised aggregate kernels: packed keys below DENSE_KEYS are counted and
+// accumulated in per-lane LDS bins addressed by the key itself (rows[key][lane], acc[a][key][lane]).
+constexpr uint32_t DENSE_KEYS = 16;
+constexpr uint32_t dense_bins_bytes(int n_accs) { return DENSE_KEYS * 64u * (4u + 8u * (uint32_t)n_accs); }
+
 // The aggregate kernel runs one list of tasks per wave-step, so that the expression
 // interpreter is instantiated once in the kernel (instruction-cache footprint).
 enum AggRole : uint8_t {
@@ -211,7 +216,7 @@ struct AggArgs {
   int32_t n_keys;
   int32_t n_accs;
   int32_t n_tasks;
-  int32_t pad0;
+  int32_t dense_off;   // byte offset of the dense-key bins in dynamic LDS (specialised kernels); 0 = none
   int64_t n_rows;
   uint32_t lds_cap;    // LDS table slots (power of two)
   uint32_t lds_limit;  // stop claiming LDS slots past this many
