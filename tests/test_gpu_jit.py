@@ -85,3 +85,23 @@ def test_background_compilation(qe, ctx):
         assert np.array_equal(got, want)
     finally:
         ctx.profile(False)
+
+
+def test_dense_key_bins(qe, jit_ctx):
+    """Aggregates whose small keys go to the per-lane LDS bins (no nullable inputs, few groups): keys on
+    both sides of the bin range and below zero in one batch, every accumulator kind, int32 and computed keys,
+    a filter in front, several batches."""
+    def cols(n, seed, lo, hi, key_dtype=np.int64):
+        a = agg_columns(n, 1, seed=seed, key_dtype=key_dtype, nulls=False)
+        a[0] = orc.Array(a[0].type, rng(seed + 1).integers(lo, hi, n).astype(key_dtype))
+        return a
+    aggs = [("max", C(2)), ("min", C(2)), ("sum", C(2)), ("count", None), ("avg", C(2)), ("sum", C(3)), ("min", C(4)), ("max", C(3))]
+    for n, lo, hi in ((1, 3, 4), (4097, 0, 16), (50_000, -5, 40), (30_000, 14, 18)):
+        run_agg(qe, jit_ctx, [cols(n, n, lo, hi)], [C(0)], aggs, hint=64, what=f"dense bins n={n} keys [{lo},{hi})")
+    run_agg(qe, jit_ctx, [cols(20_000, 5, 0, 10, np.int32), cols(7, 6, 8, 20, np.int32), cols(9000, 7, -2, 12, np.int32)], [C(0)], aggs, hint=64,
+            what="dense bins, int32 key, three batches")
+    run_agg(qe, jit_ctx, [cols(40_000, 9, 0, 1000)], [("mod", C(0), ("i64", 7))], [("sum", ("mul", C(5), C(2))), ("count", None), ("max", C(5))],
+            hint=64, pred=("gt", C(5), ("f64", 0.25)), what="dense bins, computed key, filter")
+    run_agg(qe, jit_ctx, [cols(40_000, 10, 0, 3)], [("gt", C(5), ("f64", 0.5)), C(1)], [("sum", C(2)), ("avg", C(5))], hint=64,
+            what="boolean + int32 key packed together")
+    assert any(k.startswith("qe_aggregate_jit<") for k in jit_kernels(jit_ctx))
