@@ -45,6 +45,9 @@ struct Context : std::enable_shared_from_this<Context> {
   };
   Staging staging[2];
   int next_staging = 0;
+  // Plain host memory that scans reuse for compressed bytes (a fresh allocation per column chunk
+  // costs a page fault per 4 KiB on its first touch).
+  std::vector<unsigned char> host_scratch;
   // Aggregates that returned before the device was done (QE_FLAG_DEFERRED_GROUP_COUNT) leave their
   // overflow flag in one device word (their finalize kernel adds to it); the next synchronise reads it.
   bool deferred_pending = false;

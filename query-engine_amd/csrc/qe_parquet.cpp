@@ -7,6 +7,7 @@
 
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -370,12 +371,18 @@ int walk_runs(const uint8_t *image, uint32_t off, uint32_t len, int bit_width, i
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // Host threads for the two bulk jobs of a scan: copying the file's bytes out of the page cache and
-// decompressing pages.  QE_IO_THREADS overrides the default of 8.
+// decompressing pages.  Default: the CPUs this process may run on (its affinity mask, which is what a
+// container's share shows up as), at most 16; QE_IO_THREADS overrides.
 size_t io_threads() {
   static const size_t n = [] {
     const char *e = getenv("QE_IO_THREADS");
     long v = e ? atol(e) : 0;
-    if (v <= 0) v = std::min<long>(8, std::max<long>(1, (long)std::thread::hardware_concurrency()));
+    if (v <= 0) {
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      long allowed = sched_getaffinity(0, sizeof set, &set) == 0 ? (long)CPU_COUNT(&set) : (long)std::thread::hardware_concurrency();
+      v = std::min<long>(16, std::max<long>(1, allowed));
+    }
     return (size_t)std::min<long>(v, 64);
   }();
   return n;
@@ -464,7 +471,6 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
   // the common case is tiny, so the staging buffer gets a fixed allowance and grows if it must.
   const size_t raw_len = (size_t)cm.size;
   const size_t table_room = ((size_t)1 << 16) + raw_len / 8;
-  std::unique_ptr<uint8_t[]> raw_heap;
   uint8_t *raw;
   Context::Staging *stage = nullptr;
   if (cm.codec == CODEC_NONE) {
@@ -472,8 +478,8 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
     stage = &take_staging(ctx, align16(raw_len + 16) + table_room);
     raw = (uint8_t *)stage->ptr;
   } else {
-    raw_heap.reset(new uint8_t[raw_len + 16]);
-    raw = raw_heap.get();
+    if (ctx->host_scratch.size() < raw_len + 16) ctx->host_scratch.resize(raw_len + raw_len / 4 + 16);
+    raw = ctx->host_scratch.data();
   }
   read_parallel(f, cm.start, raw, raw_len);
   std::vector<PageRec> recs;
