@@ -261,7 +261,7 @@ qe_status qe_plan_scan_memory(qe_context *ctx, qe_batch *const *batches, int32_t
  * opened (Error::IoError), QE_ERR_ARROW when it is not a Parquet file or uses a
  * feature this reader lacks (nested schemas, delta encodings, LZO / Brotli),
  * QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED at execution when a scanned column has a
- * type outside QE_TYPE_*. */
+ * type outside QE_TYPE_* (FLOAT columns are widened to QE_TYPE_FLOAT64). */
 qe_status qe_plan_scan_parquet(qe_context *ctx, const char *path, const char *const *projection, int32_t n_projection, qe_plan **out);
 /* The same scan restricted to row groups [first_row_group, first_row_group +
  * n_row_groups) of the file (clamped to what the file has): the unit by which a

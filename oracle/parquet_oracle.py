@@ -203,7 +203,7 @@ class Column:
             self.type = TIMESTAMP_NS if nanos else O.INT64
         elif physical == INT96:
             self.type = TIMESTAMP_NS
-        elif physical == DOUBLE:
+        elif physical in (DOUBLE, FLOAT):  # float32 is widened: the engine's floating type is float64
             self.type = O.FLOAT64
         elif physical == BYTE_ARRAY and (converted == 0 or (logical is not None and 1 in logical)):
             self.type = O.UTF8
@@ -332,6 +332,8 @@ class ParquetFile:
             return np.frombuffer(raw, "<i8", n).copy()
         if col.physical == DOUBLE:
             return np.frombuffer(raw, "<f8", n).copy()
+        if col.physical == FLOAT:
+            return np.frombuffer(raw, "<f4", n).astype(np.float64)
         if col.physical == INT96:  # nanoseconds of the day (u64) + Julian day (u32) -> ns since the epoch
             a = np.frombuffer(raw, np.uint8, n * 12).reshape(n, 12)
             nanos = a[:, :8].copy().view("<u8").reshape(n).astype(np.int64)

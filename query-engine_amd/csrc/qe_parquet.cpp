@@ -563,7 +563,7 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
         walks.push_back(PqWalk{body, body_len, -1, -1, dict_count});
       }
       else {
-        const uint64_t w = col.physical == PQ_INT32 ? 4 : col.physical == PQ_INT96 ? 12 : 8;
+        const uint64_t w = (col.physical == PQ_INT32 || col.physical == PQ_FLOAT) ? 4 : col.physical == PQ_INT96 ? 12 : 8;
         if (col.physical == PQ_BOOLEAN || (uint64_t)dict_count * w > body_len) bad_file("corrupt dictionary page");
       }
       continue;
@@ -845,6 +845,7 @@ std::shared_ptr<ParquetFile> parquet_open(const std::string &path) {
       case PQ_INT64: c.type = (e.logical == 8 && e.time_unit == 3) ? QE_TYPE_TIMESTAMP_NS : QE_TYPE_INT64; break;
       case PQ_INT96: c.type = QE_TYPE_TIMESTAMP_NS; break;
       case PQ_DOUBLE: c.type = QE_TYPE_FLOAT64; break;
+      case PQ_FLOAT: c.type = QE_TYPE_FLOAT64; break;  // widened on decode (arrow2 would say Float32, which the reference cannot evaluate)
       case PQ_BYTE_ARRAY: c.type = (e.converted == 0 || e.logical == 1) ? QE_TYPE_UTF8 : 0; break;
       default: c.type = 0;
     }

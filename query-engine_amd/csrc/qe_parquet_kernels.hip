@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void qe_parquet_validity_kernel(const uint8_t 
 
 __global__ __launch_bounds__(256) void qe_parquet_fixed_kernel(PqChunk c, void *out) {
   const int64_t padded = ((int64_t)c.n_rows + 63) & ~63ll;
-  const int width = c.physical == PQ_INT32 ? 4 : c.physical == PQ_INT96 ? 12 : 8;
+  const int width = (c.physical == PQ_INT32 || c.physical == PQ_FLOAT) ? 4 : c.physical == PQ_INT96 ? 12 : 8;
   for (int64_t r64 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r64 < padded; r64 += (int64_t)gridDim.x * blockDim.x) {
     const int row = (int)r64;
     const bool in = r64 < c.n_rows;
@@ -97,6 +97,8 @@ __global__ __launch_bounds__(256) void qe_parquet_fixed_kernel(PqChunk c, void *
           flag(c);
         } else if (c.physical == PQ_INT32) {
           v = load_u32(c.image, src);
+        } else if (c.physical == PQ_FLOAT) {  // widened: the engine's floating type is float64
+          v = (uint64_t)__double_as_longlong((double)__uint_as_float(load_u32(c.image, src)));
         } else if (c.physical == PQ_INT96) {
           // nanoseconds of the day, then the Julian day number: nanoseconds since 1970-01-01
           const int64_t nanos = (int64_t)load_u64(c.image, src);

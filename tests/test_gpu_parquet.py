@@ -175,6 +175,22 @@ def test_written_files(qe, ctx, tmp_path, options):
         assert vals == tbl.column(name).to_pylist(), name
 
 
+def test_float32_is_widened(qe, ctx, tmp_path):
+    """FLOAT columns arrive as Float64 (exact widening), plain and dictionary encoded, with nulls."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    n = 20_000
+    rng = np.random.default_rng(23)
+    vals = rng.standard_normal(n).astype(np.float32)
+    tbl = pa.table({"f": pa.array(vals, mask=rng.random(n) < 0.1), "g": pa.array(np.round(vals, 1))})
+    for dictionary in (False, True):
+        path = str(tmp_path / f"f32_{dictionary}.parquet")
+        pq.write_table(tbl, path, use_dictionary=dictionary, data_page_size=8192)
+        got = scan_and_compare(qe, ctx, path)[0].columns()
+        assert got[0].type == got[1].type == qe.TYPE_FLOAT64
+        assert got[0].to_pylist() == [None if v is None else float(np.float32(v)) for v in tbl.column("f").to_pylist()]
+
+
 def test_required_columns_and_projection_order(qe, ctx, tmp_path):
     import pyarrow as pa
     import pyarrow.parquet as pq
@@ -255,8 +271,8 @@ def test_errors(qe, ctx, tmp_path):
         list(qe.ParquetScanExec(ctx, str(bad)).execute())
     assert e.value.name == "ArrowError"
     # a column type the engine has no representation for: scanning it fails, leaving it out works
-    path = str(tmp_path / "f32.parquet")
-    pq.write_table(pa.table({"a": pa.array([1, 2, 3]), "f": pa.array(np.float32([1, 2, 3]))}), path)
+    path = str(tmp_path / "f16.parquet")
+    pq.write_table(pa.table({"a": pa.array([1, 2, 3]), "f": pa.array([b"ab", b"cd", b"ef"], type=pa.binary(2))}), path)
     with pytest.raises(qe.QeError) as e:
         list(qe.ParquetScanExec(ctx, path).execute())
     assert e.value.name == "PhysicalTypeNotSuported"
