@@ -167,6 +167,20 @@ def main():
             bxch = D.BlockExchange(torch, dist, xdev, world, as_block[0].shape[0], as_block[1], as_block[2], layout) if as_block else None
             torch.cuda.synchronize()
             del first, as_block
+    # QE_BENCH_SIDE_STREAM=1 (an experiment, off by default): exchange and FINAL merge of a step on a second stream (a
+    # second engine context), so that the PARTIAL aggregate of the next step - independent work - does not wait behind
+    # the collective's latency and the small kernels of the merge.  With one rank over RCCL it measured 3 % slower than
+    # one stream (event and stream hand-over costs, nothing to hide); whether a real 8-GPU all-gather's latency
+    # turns that around can only be measured on such a node.
+    two_streams = multi and deferred and backend == "nccl" and os.environ.get("QE_BENCH_SIDE_STREAM", "0") == "1"
+    if two_streams:
+        from collections import deque
+        side_stream = torch.cuda.Stream(device=dev)
+        ctx2 = qe.Context(local_rank, stream=side_stream.cuda_stream)
+        ctx2.set_flags(default_flags | qe.FLAG_DEFERRED_GROUP_COUNT)
+        in_flight = deque()
+    else:
+        side_stream, ctx2 = work_stream, ctx
 
     def step():
         part = list(local_plan().execute())[0]
@@ -181,11 +195,26 @@ def main():
         else:
             # every rank's table in one batch, rows no rank filled are zero: COUNT(*) > 0 keeps the real ones, and the
             # FINAL aggregate merges all ranks in one launch with no trip to the host in between
-            blk = batch_as_block(torch, part, 3) if bxch else None
-            merged = bxch.exchange(blk[0]) if blk else xch.exchange_merged(cols)  # the block travels as it is: nothing to pack
-            scan = qe.ScanExec(ctx, [qe.Batch.from_torch(ctx, [c.to(dev) for c in merged])])
-            real = qe.SelectionExec([scan], qe.GtExpression(C(2), qe.LiteralInt64Expression(0)))
-            final = qe.final_plan(real, 1, aggs(1), group_capacity_hint=hint)
+            if two_streams:
+                ready = torch.cuda.Event()
+                ready.record(work_stream)
+                side_stream.wait_event(ready)  # the partial table is complete before the side stream reads it
+            with torch.cuda.stream(side_stream):
+                blk = batch_as_block(torch, part, 3) if bxch else None
+                merged = bxch.exchange(blk[0]) if blk else xch.exchange_merged(cols)  # the block travels as it is: nothing to pack
+                scan = qe.ScanExec(ctx2, [qe.Batch.from_torch(ctx2, [c.to(dev) for c in merged])])
+                real = qe.SelectionExec([scan], qe.GtExpression(C(2), qe.LiteralInt64Expression(0)))
+                out = list(qe.final_plan(real, 1, aggs(1), group_capacity_hint=hint).execute())[0]
+                if two_streams:
+                    done = torch.cuda.Event()
+                    done.record(side_stream)
+                    in_flight.append((part, done))
+                    if len(in_flight) > 2:
+                        # the partial table's memory goes back to the first context's pool when `part` is dropped:
+                        # the work stream must not reuse it before the side stream has read it
+                        _, old = in_flight.popleft()
+                        work_stream.wait_event(old)
+            return out
         return list(final.execute())[0]
 
     def barrier():
@@ -193,6 +222,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()  # also reports a deferred aggregate that overflowed its table
+        if ctx2 is not ctx:
+            ctx2.synchronize()
 
     for _ in range(args.warmup):
         result = step()
@@ -207,6 +238,8 @@ def main():
     prof = ctx.profile_read()
     ctx.profile(False)
     ctx.set_flags(default_flags)
+    if ctx2 is not ctx:
+        ctx2.set_flags(default_flags)
     if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -242,6 +275,7 @@ def main():
                    "bytes_per_row": BYTES_PER_ROW["c5"], "partitioning": f"row-range x{world}",
                    "host_sync": "none inside a step (deferred group count); barrier + device synchronise around the timed steps" if deferred
                    else "per aggregate",
+                   "streams": "PARTIAL aggregate on one stream, exchange + FINAL merge on a second" if two_streams else "one",
                    "merge": (f"{'rccl' if backend == 'nccl' else backend} " + ("all_to_all by key owner" if partitioned else "all_gather") +
                              " + FINAL aggregate") if multi else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

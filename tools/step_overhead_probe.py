@@ -53,6 +53,15 @@ def main():
     sys.path.insert(0, ROOT)
     from bench import batch_as_block, column_as_tensor
     bx = {}
+    # PROBE_SIDE_STREAM=1: exchange and FINAL merge on a second stream (a second context), so that the next step's
+    # PARTIAL kernel overlaps them
+    two = os.environ.get("PROBE_SIDE_STREAM") == "1" and deferred
+    side = torch.cuda.Stream(device=dev) if two else work_stream
+    ctx2 = qe.Context(0, stream=side.cuda_stream) if two else ctx
+    if two:
+        ctx2.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_DEFERRED_GROUP_COUNT)
+    from collections import deque
+    inflight = deque()
 
     marks = {}
 
@@ -63,18 +72,30 @@ def main():
         proj = qe.ProjectionExec([sel], [C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
         part = list(qe.AggregateExec([proj], [C(0)], aggs(1), mode=qe.AGG_MODE_PARTIAL, group_capacity_hint=64).execute())[0]
         t1 = time.perf_counter()
-        blk = batch_as_block(torch, part, 3) if deferred else None
-        if blk:
-            if "x" not in bx:
-                bx["x"] = D.BlockExchange(torch, CopyDist(world), dev, world, blk[0].shape[0], blk[1], blk[2], [torch.int64, torch.float64, torch.int64])
-            merged = bx["x"].exchange(blk[0])
-        else:
-            cols = [column_as_tensor(torch, part.column_desc(i), qe) for i in range(3)]
-            merged = xch.exchange_merged(cols)
-        t2 = time.perf_counter()
-        scan = qe.ScanExec(ctx, [qe.Batch.from_torch(ctx, merged)])
-        real = qe.SelectionExec([scan], qe.GtExpression(C(2), qe.LiteralInt64Expression(0)))
-        out = list(qe.final_plan(real, 1, aggs(1), group_capacity_hint=64).execute())[0]
+        if two:
+            ready = torch.cuda.Event()
+            ready.record(work_stream)
+            side.wait_event(ready)
+        with torch.cuda.stream(side):
+            blk = batch_as_block(torch, part, 3) if deferred else None
+            if blk:
+                if "x" not in bx:
+                    bx["x"] = D.BlockExchange(torch, CopyDist(world), dev, world, blk[0].shape[0], blk[1], blk[2], [torch.int64, torch.float64, torch.int64])
+                merged = bx["x"].exchange(blk[0])
+            else:
+                cols = [column_as_tensor(torch, part.column_desc(i), qe) for i in range(3)]
+                merged = xch.exchange_merged(cols)
+            t2 = time.perf_counter()
+            scan = qe.ScanExec(ctx2, [qe.Batch.from_torch(ctx2, merged)])
+            real = qe.SelectionExec([scan], qe.GtExpression(C(2), qe.LiteralInt64Expression(0)))
+            out = list(qe.final_plan(real, 1, aggs(1), group_capacity_hint=64).execute())[0]
+            if two:
+                done = torch.cuda.Event()
+                done.record(side)
+                inflight.append((part, done))
+                if len(inflight) > 2:  # the partial table's block goes back to the first context's pool: not before the side stream has read it
+                    _, old = inflight.popleft()
+                    work_stream.wait_event(old)
         t3 = time.perf_counter()
         for name, dt in (("partial_plan", t1 - t0), ("exchange_host_side", t2 - t1), ("final_plan", t3 - t2)):
             marks[name] = marks.get(name, 0.0) + dt
@@ -94,6 +115,7 @@ def main():
     prof = ctx.profile_read()
     kern = sum(v["ms"] for kk, v in prof.items() if kk.startswith("qe_aggregate_static")) / steps
     ctx.synchronize()
+    ctx2.synchronize()
     cols = out.columns()
     real = cols[2].values > 0
     assert int(real.sum()) == 10 and int(cols[2].values[real].sum()) * 1 > 0, "merged result is wrong"
