@@ -1,21 +1,24 @@
 // gfx950 kernels of the Parquet scan leaf (see qe_parquet_kernels.h for the host/device split).
 // All of them are one-thread-per-row streaming kernels: a row finds its page and its run by binary
 // search over small host-built tables (L1/L2 resident), reads its value from the chunk image and
-// writes the Arrow buffer.  Value sections in a Parquet file have no alignment at all, so every
-// multi-byte read goes through aligned dword loads and a byte funnel shift.
+// writes the Arrow buffer.  Value sections in a Parquet file have no alignment at all: multi-byte
+// reads are misaligned global loads.
 #include "qe_parquet_kernels.h"
 
 namespace qe {
 namespace {
 
+// (The hardware takes misaligned global loads; given a copy from an address of unknown alignment the
+// compiler emits one dword / dwordx2 load, not byte loads.)
 __device__ __forceinline__ uint32_t load_u32(const uint8_t *image, uint32_t off) {
-  const uint32_t *b = (const uint32_t *)(image + (off & ~3u));
-  return __builtin_amdgcn_alignbyte(b[1], b[0], off & 3u);
+  uint32_t v;
+  __builtin_memcpy(&v, image + off, 4);
+  return v;
 }
 __device__ __forceinline__ uint64_t load_u64(const uint8_t *image, uint32_t off) {
-  const uint32_t *b = (const uint32_t *)(image + (off & ~3u));
-  const uint32_t w0 = b[0], w1 = b[1], w2 = b[2], sh = off & 3u;
-  return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32);
+  uint64_t v;
+  __builtin_memcpy(&v, image + off, 8);
+  return v;
 }
 
 // Last element of a sorted table whose key is <= x (the table's first key is <= x by construction).
@@ -73,8 +76,13 @@ __global__ __launch_bounds__(256) void qe_parquet_fixed_kernel(PqChunk c, void *
     const int row = (int)r64;
     const bool in = r64 < c.n_rows;
     uint64_t v = 0;
+    // The page of the wave's first row is nearly always the page of all its rows: looked up once, with scalar
+    // loads; a lane whose row lies in another page searches for itself.
+    const int row_first = __builtin_amdgcn_readfirstlane(row < c.n_rows ? row : c.n_rows - 1);
+    PqPage p = c.pages[upper_slot(c.pages, 0, c.n_pages, row_first, [](const PqPage &q) { return q.first_row; })];
     if (in && valid_at(c, row)) {
-      const PqPage p = c.pages[upper_slot(c.pages, 0, c.n_pages, row, [](const PqPage &q) { return q.first_row; })];
+      if (row < p.first_row || row >= p.first_row + p.num_rows)
+        p = c.pages[upper_slot(c.pages, 0, c.n_pages, row, [](const PqPage &q) { return q.first_row; })];
       const int vi = rank_of(c, row) - rank_of(c, p.first_row);
       if (p.encoding == PQ_ENC_RLE_BOOL) {
         v = run_value(c.image, c.runs, p.run_begin, p.run_end, vi, 1);
