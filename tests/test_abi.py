@@ -56,3 +56,23 @@ def test_invalid_arguments_do_not_crash(qe):
     assert qe.lib.qe_agg_expr_new(3, None, ctypes.byref(h)) == 40  # only COUNT may omit its input
     assert qe.lib.qe_plan_selection(None, qe.ColumnExpression(0)._build(), ctypes.byref(h)) == 18  # MissingInputPhysicalPlan
     assert b"Selection" in qe.lib.qe_last_error_message()
+
+
+def test_constants_match_the_header(qe):
+    """Every QE_* enumerator the Python mirror carries has the header's value."""
+    header = open(os.path.join(ROOT, "include", "qe_gpu.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    values = {name: int(v) for name, v in re.findall(r"\b(QE_[A-Z0-9_]+)\s*=\s*(\d+)", header)}
+    assert len(values) >= 50
+    mirror = {"QE_TYPE_": "TYPE_", "QE_OP_": "OP_", "QE_AGG_MODE_": "AGG_MODE_", "QE_AGG_": "AGG_", "QE_FLAG_": "FLAG_", "QE_MEM_": "MEM_"}
+    checked = 0
+    for name, value in values.items():
+        for c_prefix, py_prefix in mirror.items():
+            if name.startswith(c_prefix):
+                py = py_prefix + name[len(c_prefix):]
+                if hasattr(qe, py):
+                    assert getattr(qe, py) == value, f"{py} != {name}"
+                    checked += 1
+                break
+    assert checked >= 30
+    assert qe.QE_OK == values["QE_OK"] and qe.QE_END == values["QE_END"]
