@@ -625,11 +625,22 @@ class AggregateExec(PhysicalPlan):
         # utf8 arrays, so the reference groups by strings (its test_max groups by `country`).
         dictionary = {}
         utf8_key = False
+        tuple_types = None  # key tuples that do not fit 64 bits: dictionary-encoded as tuples
         for ch in chunks:
             gk, ai = self._inputs(ch)
-            if any(a.type == UTF8 for a in gk):
-                if len(gk) != 1:
-                    raise OracleError("PhysicalTypeNotSuported", "a Utf8 group key must be the only group expression")
+            bits = sum({INT32: 32, INT64: 64, BOOLEAN: 1, UTF8: 64}.get(a.type, 999) for a in gk)
+            if len(gk) > 1 and (bits > 64 or any(a.type == UTF8 for a in gk)):
+                for a in gk:
+                    if a.type not in (INT32, INT64, BOOLEAN, UTF8):
+                        raise OracleError("PhysicalTypeNotSuported", _TYPE_NAME[a.type])
+                tuple_types = [a.type for a in gk]
+                cols_py = [a.strings() if a.type == UTF8 else a.values.tolist() for a in gk]
+                valid = None
+                for a in gk:
+                    valid = _and_validity(valid, a.validity)
+                codes = np.array([dictionary.setdefault(t, len(dictionary)) for t in zip(*cols_py)], dtype=np.int64)
+                gk = [Array(INT64, codes, valid)]
+            elif any(a.type == UTF8 for a in gk):
                 utf8_key = True
                 codes = np.array([dictionary.setdefault(sv, len(dictionary)) for sv in gk[0].strings()], dtype=np.int64)
                 gk = [Array(INT64, codes, gk[0].validity)]
@@ -652,6 +663,15 @@ class AggregateExec(PhysicalPlan):
             for sv, code in dictionary.items():
                 words[code] = sv
             cols[0] = Array.from_python([words[int(c)] for c in cols[0].values])
+        if tuple_types is not None:
+            tuples = [None] * len(dictionary)
+            for t, code in dictionary.items():
+                tuples[code] = t
+            picked = [tuples[int(c)] for c in cols[0].values]
+            cols = []
+            for i, t in enumerate(tuple_types):
+                vals = [p[i] for p in picked]
+                cols.append(Array.from_python(vals) if t == UTF8 else Array(t, np.array(vals, dtype={INT32: np.int32, INT64: np.int64, BOOLEAN: np.bool_}[t])))
         for j, e in enumerate(self.agg_exprs):
             arrs = per_agg[j]
             if e.expr is None:

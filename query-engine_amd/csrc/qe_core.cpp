@@ -248,6 +248,14 @@ ExprPtr make_hash_utf8(ExprPtr column) {
   return n;
 }
 
+ExprPtr make_key_hash(ExprPtr before, ExprPtr column) {
+  auto n = std::make_shared<Expr>();
+  n->kind = EK_KEY_HASH;
+  n->l = std::move(before);
+  n->r = std::move(column);
+  return n;
+}
+
 ExprPtr make_rowid(int64_t base) {
   auto n = std::make_shared<Expr>();
   n->kind = EK_ROWID;
@@ -294,6 +302,7 @@ std::string expr_to_string(const ExprPtr &e) {
       o << expr_to_string(e->l) << " " << op_symbol(e->op) << " " << expr_to_string(e->r);
       break;
     case EK_HASH_UTF8: o << "hash(" << expr_to_string(e->l) << ")"; break;
+    case EK_KEY_HASH: o << "keyhash(" << (e->l ? expr_to_string(e->l) + ", " : std::string()) << expr_to_string(e->r) << ")"; break;
     case EK_ROWID: o << "rowid(" << e->ival << ")"; break;
   }
   return o.str();
@@ -304,6 +313,7 @@ bool expr_is_scalar(const ExprPtr &e) {
     case EK_COLUMN: return false;
     case EK_LITERAL: return true;
     case EK_HASH_UTF8:
+    case EK_KEY_HASH:
     case EK_ROWID: return false;
     default: return expr_is_scalar(e->l) && (e->to_f64 || expr_is_scalar(e->r));
   }
@@ -326,6 +336,13 @@ int expr_type(const ExprPtr &e, const Schema &schema) {
       return QE_TYPE_INT64;
     case EK_ROWID:
       return QE_TYPE_INT64;
+    case EK_KEY_HASH: {
+      if (e->l) (void)expr_type(e->l, schema);
+      const int t = expr_type(e->r, schema);
+      if (e->r->kind != EK_COLUMN || !(t == QE_TYPE_INT32 || t == QE_TYPE_INT64 || t == QE_TYPE_BOOLEAN || t == QE_TYPE_UTF8))
+        fail(QE_ERR_INTERNAL, "key hash of something that is not a key column");
+      return QE_TYPE_INT64;
+    }
     default: {
       int lt = expr_type(e->l, schema);
       if (e->to_f64) {
@@ -363,6 +380,7 @@ bool expr_nullable(const ExprPtr &e, const Schema &schema) {
     case EK_COLUMN: return e->index >= 0 && e->index < (int)schema.size() && schema[e->index].nullable;
     case EK_LITERAL: return !e->valid;
     case EK_HASH_UTF8: return expr_nullable(e->l, schema);
+    case EK_KEY_HASH: return (e->l && expr_nullable(e->l, schema)) || expr_nullable(e->r, schema);
     case EK_ROWID: return false;
     default: {
       if (e->to_f64) return expr_nullable(e->l, schema);
@@ -383,7 +401,7 @@ ExprPtr expr_substitute(const ExprPtr &e, const std::vector<ExprPtr> &outputs) {
       return e;
     default: {
       auto n = std::make_shared<Expr>(*e);
-      n->l = expr_substitute(e->l, outputs);
+      if (e->l) n->l = expr_substitute(e->l, outputs);
       if (e->r) n->r = expr_substitute(e->r, outputs);
       return n;
     }
@@ -495,6 +513,10 @@ static int count_nodes(const ExprPtr &e) {
 static void collect_cols(const ExprPtr &e, std::map<int, int> &seen) {
   if (e->kind == EK_COLUMN) seen[e->index] = 1;
   if (e->kind == EK_HASH_UTF8) collect_cols(e->l, seen);
+  if (e->kind == EK_KEY_HASH) {
+    if (e->l) collect_cols(e->l, seen);
+    collect_cols(e->r, seen);
+  }
   if (e->kind == EK_BINARY) {
     collect_cols(e->l, seen);
     if (e->r) collect_cols(e->r, seen);
@@ -620,6 +642,23 @@ void Compiler::emit(const ExprPtr &e, int depth) {
     case EK_HASH_UTF8: {
       if (e->l->kind != EK_COLUMN) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "A Utf8 group key must be a column.");
       push_insn(OP_HASH_UTF8, depth, (uint32_t)col_slot(e->l->index));
+      return;
+    }
+    case EK_KEY_HASH: {
+      // h = mix64(h_before * K + part), h_first = mix64(part + K); part = the column's value (a string's hash)
+      const uint64_t K = 0x9E3779B97F4A7C15ull;
+      if (depth + 1 >= VM_MAX_DEPTH) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression is nested too deeply.");
+      if (e->l) {
+        emit(e->l, depth);
+        push_insn(OP_PUSH_LIT, depth + 1, lit_slot(K));
+        push_insn(OP_MUL_I64, depth + 2, 0);
+      } else {
+        push_insn(OP_PUSH_LIT, depth, lit_slot(K));
+      }
+      if (expr_type(e->r, schema) == QE_TYPE_UTF8) push_insn(OP_HASH_UTF8, depth + 1, (uint32_t)col_slot(e->r->index));
+      else emit(e->r, depth + 1);
+      push_insn(OP_ADD_I64, depth + 2, 0);
+      push_insn(OP_MIX64, depth + 1, 0);
       return;
     }
     case EK_ROWID: {

@@ -125,7 +125,10 @@ enum ExprKind {
   EK_BINARY = 2,
   // internal, made by the aggregate lowering only:
   EK_HASH_UTF8 = 3,  // 64-bit hash of the utf8 column `l` (a string group key is aggregated by its hash)
-  EK_ROWID = 4       // global row number: `ival` (rows of the earlier batches) + row in the batch
+  EK_ROWID = 4,      // global row number: `ival` (rows of the earlier batches) + row in the batch
+  // 64-bit hash of a tuple of key columns, built column by column: `l` = hash of the columns before
+  // (null for the first), `r` = the column (any key type, utf8 included)
+  EK_KEY_HASH = 5
 };
 
 struct Expr;
@@ -157,6 +160,7 @@ ExprPtr make_lit_bool(bool v);
 ExprPtr make_lit_utf8(const std::string &s);
 ExprPtr make_binary(int op, ExprPtr l, ExprPtr r);
 ExprPtr make_hash_utf8(ExprPtr column);
+ExprPtr make_key_hash(ExprPtr before, ExprPtr column);
 ExprPtr make_rowid(int64_t base);
 std::string expr_to_string(const ExprPtr &e);
 bool expr_is_scalar(const ExprPtr &e);

@@ -361,7 +361,7 @@ __device__ __forceinline__ void vm_slow(uint32_t op, uint32_t d, uint32_t arg, c
   c.active = c0.active;
   c.lane = opaque(c0.lane);
   const bool is_push = (op <= OP_PUSH_ROWID) || (op >= OP_UTF8_EQ_LIT && op <= OP_HASH_UTF8);
-  const bool is_unary = op == OP_I64_TO_F64;
+  const bool is_unary = op == OP_I64_TO_F64 || op == OP_MIX64;
   Slot a, b;
   uint32_t dst;
   if (is_push) {
@@ -482,6 +482,11 @@ __device__ __forceinline__ void vm_slow(uint32_t op, uint32_t d, uint32_t arg, c
     case OP_I64_TO_F64: {
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) a.v[j] = d2u((double)(int64_t)a.v[j]);
+      break;
+    }
+    case OP_MIX64: {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) a.v[j] = mix64(a.v[j]);
       break;
     }
     case OP_DIV_F64: {

@@ -198,6 +198,21 @@ static Column utf8_gather_rows(Context *ctx, const std::vector<Utf8KeySource> &s
   return c;
 }
 
+// The same for a fixed-width key column (Int32 / Int64 / Boolean; keys of surviving groups are never null).
+static Column fixed_gather_rows(Context *ctx, int type, const std::vector<Utf8KeySource> &sources, const int64_t *ids, int64_t m) {
+  std::vector<FixedSource> table;
+  for (auto &s : sources) table.push_back(FixedSource{s.col.values_ptr(), s.first_row});
+  BufferPtr dev_table = device_buffer(ctx, table.size() * sizeof(FixedSource) + 16);
+  QE_HIP(hipMemcpyAsync(dev_table->ptr, table.data(), table.size() * sizeof(FixedSource), hipMemcpyHostToDevice, ctx->stream));
+  Column c = make_fixed_column(ctx, type, m, false, false);
+  finish_fixed_column(c, m);
+  ctx->prof_begin("qe_gather_rows_fixed_kernel");
+  QE_HIP(launch_gather_rows_fixed((const FixedSource *)dev_table->ptr, (int)table.size(), ids, m, type_width(type), c.values->ptr, ctx->stream));
+  ctx->prof_end();
+  ctx->sync();  // `table` (host) has been read; `dev_table` goes back to the pool on return
+  return c;
+}
+
 // ---------------------------------------------------------------- lowering
 // Expression trees -> kernel arguments, apart from output buffers: those come from `sink`, so
 // that the same code serves execution (buffers from the pool) and qe_lowering_describe (none).
@@ -434,8 +449,13 @@ struct AggSpec {
   std::vector<ExprPtr> key_exprs;
   std::vector<AccDesc> accs;
   std::vector<FinOut> outs;  // pointers filled at finalize time
-  int utf8_key_out = -1;     // output column that holds representative row numbers of a utf8 key
-  int utf8_key_col = -1;     // ... and the source column the strings come from
+  // Key columns that are not unpacked from the 64-bit group key (a string key, or a tuple of keys identified by
+  // its hash) but gathered from the source batches by a representative row of the group: output column (it holds
+  // those row numbers until the gather), source column, type.
+  struct KeyGather {
+    int out, col, type;
+  };
+  std::vector<KeyGather> key_gathers;
 };
 
 static int add_acc(AggSpec &spec, uint8_t op, int in_type, bool track_nn, const ExprPtr &input) {
@@ -489,7 +509,44 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
   AggSpec spec;
   int shift = 0;
   if ((int)groups.size() > VM_MAX_KEYS) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many group expressions.");
-  for (size_t g = 0; g < groups.size(); ++g) {
+  // Keys that do not fit the 64-bit packed key - a string next to other keys, several strings, more than 64
+  // bits of integers - are identified by a 64-bit hash of the tuple, as the reference identifies every group
+  // (physical_plan/mod.rs:317-358 sums per-column hashes); the key columns of the output are gathered from a
+  // representative row of each group, so every key must be a plain column.
+  {
+    int total_bits = 0, strings = 0;
+    std::vector<ExprPtr> norm;
+    for (auto &g : groups) {
+      norm.push_back(expr_normalize(g, flags));
+      const int t = expr_type(norm.back(), schema);
+      strings += t == QE_TYPE_UTF8;
+      total_bits += t == QE_TYPE_INT32 ? 32 : t == QE_TYPE_INT64 ? 64 : t == QE_TYPE_BOOLEAN ? 1 : t == QE_TYPE_UTF8 ? 64 : 0;
+    }
+    if (groups.size() > 1 && (strings > 0 || total_bits > 64)) {
+      ExprPtr h;
+      for (auto &e : norm) {
+        const int t = expr_type(e, schema);
+        if (!(t == QE_TYPE_INT32 || t == QE_TYPE_INT64 || t == QE_TYPE_BOOLEAN || t == QE_TYPE_UTF8))
+          fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, std::string("Physical type `") + type_name(t) + "` is not supported as a group key.");
+        if (e->kind != EK_COLUMN)
+          fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "Group keys wider than 64 bits in all (or including a Utf8 column) must be plain columns.");
+        h = make_key_hash(h, e);
+      }
+      VmKey k{};
+      k.type = (uint8_t)QE_TYPE_INT64;
+      k.shift = 0;
+      k.bits = 64;
+      spec.keys.push_back(k);
+      spec.key_exprs.push_back(h);
+      const int a = add_acc(spec, ACC_MIN, QE_TYPE_INT64, false, make_rowid(row_base));
+      for (auto &e : norm) {
+        spec.key_gathers.push_back(AggSpec::KeyGather{(int)spec.outs.size(), e->index, expr_type(e, schema)});
+        spec.outs.push_back(fin(FIN_ACC_ORD, QE_TYPE_INT64, a, a, CNT_ROWS, NULL_NEVER));
+      }
+      shift = 64;
+    }
+  }
+  for (size_t g = 0; g < groups.size() && spec.key_gathers.empty(); ++g) {
     ExprPtr e = expr_normalize(groups[g], flags);
     int t = expr_type(e, schema);
     if (t == QE_TYPE_UTF8) {
@@ -505,8 +562,7 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
       spec.keys.push_back(k);
       spec.key_exprs.push_back(make_hash_utf8(e));
       int a = add_acc(spec, ACC_MIN, QE_TYPE_INT64, false, make_rowid(row_base));
-      spec.utf8_key_out = (int)spec.outs.size();
-      spec.utf8_key_col = e->index;
+      spec.key_gathers.push_back(AggSpec::KeyGather{(int)spec.outs.size(), e->index, QE_TYPE_UTF8});
       spec.outs.push_back(fin(FIN_ACC_ORD, QE_TYPE_INT64, a, a, CNT_ROWS, NULL_NEVER));
       shift = 64;
       continue;
@@ -770,7 +826,7 @@ struct AggState {
   AggSpec spec;
   AggTable table{};
   BufferPtr table_buf;
-  std::vector<Utf8KeySource> key_sources;
+  std::vector<std::vector<Utf8KeySource>> key_sources;  // per gathered key column: its source in every batch
   int64_t row_base = 0;
   int deferred_finishes = 0;
   BufferPtr deferred_block;  // output block of the deferred mode, cleared by the table's init launch
@@ -815,7 +871,8 @@ struct AggState {
     }
     Schema schema = schema_of(in);
     AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode, row_base);
-    if (bspec.utf8_key_col >= 0) key_sources.push_back(Utf8KeySource{in.cols[bspec.utf8_key_col], row_base});
+    key_sources.resize(bspec.key_gathers.size());
+    for (size_t i = 0; i < bspec.key_gathers.size(); ++i) key_sources[i].push_back(Utf8KeySource{in.cols[bspec.key_gathers[i].col], row_base});
     row_base += in.rows;
     if (!have_table) {
       spec = bspec;
@@ -894,7 +951,7 @@ struct AggState {
     return total;
   }
   bool deferred_wanted() const {
-    return table.cap + 1 <= (1u << 16) && (ctx->flags & QE_FLAG_DEFERRED_GROUP_COUNT) && spec.utf8_key_out < 0;
+    return table.cap + 1 <= (1u << 16) && (ctx->flags & QE_FLAG_DEFERRED_GROUP_COUNT) && spec.key_gathers.empty();
   }
 
   bool finish_deferred(Batch &result) {
@@ -989,9 +1046,11 @@ struct AggState {
     }
     result.rows = (int64_t)n_groups;
     for (auto &c : result.cols) finish_fixed_column(c, (int64_t)n_groups);
-    if (spec.utf8_key_out >= 0) {
-      Column &ids = result.cols[spec.utf8_key_out];
-      result.cols[spec.utf8_key_out] = utf8_gather_rows(ctx, key_sources, (const int64_t *)ids.values->ptr, (int64_t)n_groups);
+    for (size_t i = 0; i < spec.key_gathers.size(); ++i) {
+      const AggSpec::KeyGather &kg = spec.key_gathers[i];
+      const Column ids = result.cols[kg.out];  // representative row numbers; the buffer lives until the gather is done
+      result.cols[kg.out] = kg.type == QE_TYPE_UTF8 ? utf8_gather_rows(ctx, key_sources[i], (const int64_t *)ids.values->ptr, (int64_t)n_groups)
+                                                    : fixed_gather_rows(ctx, kg.type, key_sources[i], (const int64_t *)ids.values->ptr, (int64_t)n_groups);
     }
     if (!eager) ctx->sync();
     return true;

@@ -65,6 +65,13 @@ struct Utf8Source {
 };
 hipError_t launch_utf8_gather_rows(const Utf8Source *sources, int n_sources, const int64_t *ids, int64_t m, int32_t *out_lengths,
                                    const int32_t *dst_offsets, uint8_t *dst_bytes, hipStream_t stream);
+// The same for fixed-width columns: width 8 or 4 bytes, 0 = bit-packed booleans (`out` zeroed by the caller).
+struct FixedSource {
+  const void *values;
+  int64_t first_row;
+};
+hipError_t launch_gather_rows_fixed(const FixedSource *sources, int n_sources, const int64_t *ids, int64_t m, int width, void *out,
+                                    hipStream_t stream);
 // Broadcast one utf8 literal to `n` rows (scalar_to_array for Utf8, columnar_value.rs:40-50).
 hipError_t launch_utf8_broadcast(const uint8_t *lit, int32_t len, int64_t n, int32_t *out_offsets, uint8_t *out_bytes,
                                  hipStream_t stream);

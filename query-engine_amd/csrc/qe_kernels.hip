@@ -576,6 +576,20 @@ __global__ __launch_bounds__(256) void qe_finalize_kernel(const FinalizeArgs A) 
   }
 }
 
+// Fixed-width values (4 or 8 bytes; width 0 = bit-packed booleans) of the rows `ids` (global row numbers over
+// several source columns): the output key columns of an aggregate whose groups are identified by a hash.
+__global__ void qe_gather_rows_fixed_kernel(const FixedSource *sources, int n_sources, const int64_t *ids, int64_t m, int width, void *out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t id = ids[i];
+    int s = n_sources - 1;
+    while (s > 0 && sources[s].first_row > id) --s;
+    const int64_t r = id - sources[s].first_row;
+    if (width == 8) ((uint64_t *)out)[i] = ((const uint64_t *)sources[s].values)[r];
+    else if (width == 4) ((uint32_t *)out)[i] = ((const uint32_t *)sources[s].values)[r];
+    else if ((((const uint8_t *)sources[s].values)[r >> 3] >> (r & 7)) & 1u) atomicOr((uint32_t *)out + (i >> 5), 1u << (i & 31));
+  }
+}
+
 // ------------------------------------------------------------- utf8 helpers
 __global__ void qe_utf8_gather_lengths_kernel(const int32_t *offsets, const uint8_t *validity, const int64_t *idx,
                                               int64_t m, int32_t *out_lengths, uint32_t *out_validity) {
@@ -1012,6 +1026,13 @@ hipError_t launch_utf8_gather_rows(const Utf8Source *sources, int n_sources, con
   if (m <= 0) return hipSuccess;
   hipLaunchKernelGGL(qe_utf8_gather_rows_kernel, dim3(grid_for(m, 256, 4096)), dim3(256), 0, stream, sources, n_sources, ids, m, out_lengths,
                      dst_offsets, dst_bytes);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_rows_fixed(const FixedSource *sources, int n_sources, const int64_t *ids, int64_t m, int width, void *out,
+                                    hipStream_t stream) {
+  if (m <= 0) return hipSuccess;
+  hipLaunchKernelGGL(qe_gather_rows_fixed_kernel, dim3(grid_for(m, 256, 4096)), dim3(256), 0, stream, sources, n_sources, ids, m, width, out);
   return hipGetLastError();
 }
 

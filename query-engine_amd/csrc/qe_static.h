@@ -136,6 +136,9 @@ __device__ __forceinline__ void eval_static(const VmProgram &P, const RowCtx &c,
     } else if constexpr (op == OP_I64_TO_F64) {
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) S[d - 1].v[j] = d2u((double)(int64_t)S[d - 1].v[j]);
+    } else if constexpr (op == OP_MIX64) {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) S[d - 1].v[j] = mix64(S[d - 1].v[j]);
     } else if constexpr (op == OP_DIV_F64) {
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) S[d - 2].v[j] = d2u(u2d(S[d - 2].v[j]) / u2d(S[d - 1].v[j]));

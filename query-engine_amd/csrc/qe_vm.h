@@ -55,6 +55,7 @@ enum VmOp : uint32_t {
   OP_I64_TO_F64,                   // top slot: int64 -> float64 (AVG over integers)
   // pushes out of the per-step column cache (arg = cache slot)
   OP_PUSH_CACHED64, OP_PUSH_CACHED32, OP_PUSH_CACHEDBOOL,
+  OP_MIX64,                        // top slot: 64-bit finaliser of a hash (composite group keys)
   OP_COUNT_
 };
 

@@ -425,9 +425,62 @@ def test_utf8_group_key(qe, ctx):
     got = _by_key(list(build2(qe, qe.ScanExec(ctx, [gpu_batch(qe, ctx, keyed)])).execute())[0].columns(), False)
     assert got == want
     with pytest.raises(qe.QeError) as e:
-        list(qe.AggregateExec([qe.ScanExec(ctx, [gpu_batch(qe, ctx, arrays)])], [qe.ColumnExpression(ci), qe.ColumnExpression(COL["id"])],
+        # next to a string key every key must be a plain column (the output keys are gathered from the source)
+        computed = qe.AddExpression(qe.ColumnExpression(COL["id"]), qe.LiteralIntegerExpression(1))
+        list(qe.AggregateExec([qe.ScanExec(ctx, [gpu_batch(qe, ctx, arrays)])], [qe.ColumnExpression(ci), computed],
                               [qe.MaxExpression(qe.ColumnExpression(si))]).execute())
     assert e.value.name == "PhysicalTypeNotSuported"
+
+
+def _rows_by_key(cols, n_keys, oracle):
+    lists = [c.to_pylist() for c in cols]
+    out = {}
+    for row in zip(*lists):
+        out[tuple(row[:n_keys])] = row[n_keys:]
+    assert len(out) == len(lists[0])
+    return out
+
+
+def test_composite_group_keys(qe, ctx):
+    """Key tuples that do not fit the 64-bit packed key - strings next to other keys, two strings, two Int64 - are
+    grouped by a hash of the tuple and come back as gathered key columns; null in any key drops the row."""
+    r = rng(77)
+    n = 30_000
+    words = ["", "a", "ab", "Ünïcode", "a longer string with spaces", "z" * 40]
+
+    def table(n, seed):
+        r = rng(seed)
+        s1 = [None if x == 0 else words[x % len(words)] for x in r.integers(0, 50, n)]
+        s2 = ["k%d" % x for x in r.integers(0, 4, n)]
+        return [orc.Array.from_python(s1), orc.Array.from_python(s2), orc.Array(orc.INT32, r.integers(-2, 3, n).astype(np.int32), r.random(n) > 0.05),
+                orc.Array(orc.INT64, r.integers(-2 ** 62, 2 ** 62, n) // 2 ** 60 * 2 ** 60), orc.Array(orc.BOOLEAN, r.random(n) < 0.5),
+                orc.Array(orc.FLOAT64, r.uniform(-10, 10, n), r.random(n) > 0.1), orc.Array(orc.INT64, r.integers(-100, 100, n))]
+    aggs = [("sum", C(5)), ("count", C(5)), ("count", None), ("min", C(5)), ("max", C(6)), ("avg", C(6))]
+    parts = [table(n, 1), table(7, 2), table(n // 2, 3)]
+    for keys in ([0, 2], [0, 1], [3, 6], [1, 4, 2, 3], [0, 3]):
+        def build(m, scan):
+            return m.AggregateExec([scan], [mk(m, C(k)) for k in keys], [mk(m, a) for a in aggs])
+        want = _rows_by_key(list(build(orc, orc.ScanExec([orc.Chunk(p) for p in parts])).execute())[0].arrays, len(keys), True)
+        got = _rows_by_key(list(build(qe, qe.ScanExec(ctx, [gpu_batch(qe, ctx, p) for p in parts])).execute())[0].columns(), len(keys), False)
+        assert set(got) == set(want), keys
+        for key, w in want.items():
+            g = got[key]
+            assert g[1] == w[1] and g[2] == w[2] and g[3] == w[3] and g[4] == w[4], (keys, key)
+            for a, b in ((g[0], w[0]), (g[5], w[5])):
+                assert (a is None) == (b is None) and (a is None or abs(a - b) <= 1e-12 * max(1.0, abs(b)) * 100), (keys, key)
+    # PARTIAL per batch -> FINAL over the gathered key columns
+    keys = [1, 2, 0]
+    partials = []
+    for p in parts:
+        plan = qe.AggregateExec([qe.ScanExec(ctx, [gpu_batch(qe, ctx, p)])], [mk(qe, C(k)) for k in keys], [mk(qe, a) for a in aggs], mode=qe.AGG_MODE_PARTIAL)
+        partials += list(plan.execute())
+    merged = list(qe.final_plan(qe.ScanExec(ctx, partials), len(keys), [mk(qe, a) for a in aggs]).execute())[0]
+    want = _rows_by_key(list(orc.AggregateExec([orc.ScanExec([orc.Chunk(p) for p in parts])], [mk(orc, C(k)) for k in keys], [mk(orc, a) for a in aggs]).execute())[0].arrays,
+                        len(keys), True)
+    got = _rows_by_key(merged.columns(), len(keys), False)
+    assert set(got) == set(want)
+    for key, w in want.items():
+        assert got[key][1:5] == w[1:5], key
 
 
 def test_c_abi_from_plain_c():
