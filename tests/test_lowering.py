@@ -72,6 +72,13 @@ def test_runtime_compilation_offline(qe):
     assert nk == 1
     nk, _ = qe.compile_lowering([i32] * 9, exprs=[qe.AddExpression(C(i), C(8 - i)) for i in range(4)])  # 8 columns, 6 cached
     assert nk == 1
+    # a key tuple wider than 64 bits: grouped by a hash of the tuple (multiply, add, OP_MIX64), still a compiled kernel;
+    # with a string in the tuple the hash of the string needs the general kernels
+    nk, _ = qe.compile_lowering([i64, i64, i32, f64], group_exprs=[C(0), C(1), C(2)], agg_exprs=[qe.SumExpression(C(3))])
+    assert nk == 1
+    d = qe.describe_lowering([i64, i64, f64], group_exprs=[C(0), C(1)], agg_exprs=[qe.SumExpression(C(2))])
+    assert d["launches"][0]["specialisable"] == 1
+    assert qe.compile_lowering([utf8, i32, f64], group_exprs=[C(0), C(1)], agg_exprs=[qe.SumExpression(C(2))]) == (0, 0)
     # utf8 comparisons run on the general kernels only
     assert qe.compile_lowering([utf8, i32], exprs=[qe.EqExpression(C(0), C(0))]) == (0, 0)
     d = qe.describe_lowering([utf8, i32], exprs=[qe.EqExpression(C(0), C(0))])
