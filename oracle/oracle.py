@@ -297,7 +297,8 @@ class _Comparison(PhysicalExpression):
             if arr.type != sc.type:
                 raise OracleError("PhysicalTypeNotSuported", _TYPE_NAME[arr.type])
             if sc.value is None:
-                raise OracleError("ScalarToArrayError", "null scalar")
+                # arrow2's *_scalar comparisons: a null scalar gives an all-null result
+                return ColumnarValue(array=Array(BOOLEAN, np.zeros(len(arr), np.bool_), np.zeros(len(arr), np.bool_)))
             return ColumnarValue(array=_cmp_arrays(op, arr, _scalar_as_array1(sc), True))
         a, b = l.scalar, r.scalar
         if op in (OP_EQ, OP_NEQ):

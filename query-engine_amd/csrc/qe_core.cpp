@@ -2,6 +2,7 @@
 // expression -> stack-machine compiler.
 #include "qe_core.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -506,29 +507,61 @@ ExprPtr expr_normalize(const ExprPtr &e, uint32_t flags) {
 // ----------------------------------------------------------------- compiler
 Compiler::Compiler(Context *c, const Batch *b) : ctx(c), batch(b), schema(schema_of(*b)) {}
 
-static int count_nodes(const ExprPtr &e) {
-  if (e->kind != EK_BINARY) return 1;
-  return 1 + count_nodes(e->l) + (e->r ? count_nodes(e->r) : 0);
-}
-static void collect_cols(const ExprPtr &e, std::map<int, int> &seen) {
+void expr_columns(const ExprPtr &e, std::map<int, int> &seen) {
+  if (!e) return;
   if (e->kind == EK_COLUMN) seen[e->index] = 1;
-  if (e->kind == EK_HASH_UTF8) collect_cols(e->l, seen);
-  if (e->kind == EK_KEY_HASH) {
-    if (e->l) collect_cols(e->l, seen);
-    collect_cols(e->r, seen);
-  }
-  if (e->kind == EK_BINARY) {
-    collect_cols(e->l, seen);
-    if (e->r) collect_cols(e->r, seen);
+  if (e->kind == EK_HASH_UTF8 || e->kind == EK_KEY_HASH || e->kind == EK_BINARY) {
+    expr_columns(e->l, seen);
+    expr_columns(e->r, seen);
   }
 }
 
+ExprCost expr_cost(const ExprPtr &e, const Schema &schema) {
+  ExprCost c;
+  switch (e->kind) {
+    case EK_COLUMN:
+    case EK_HASH_UTF8: c.insns = 1, c.slots = 1; return c;
+    case EK_LITERAL:
+      if (e->valid) c.insns = 1, c.lits = 1, c.slots = 1;
+      else c.insns = 3, c.lits = 1, c.slots = 2;  // a null is made by dividing zero by zero
+      return c;
+    case EK_ROWID:
+      c.insns = e->ival ? 3 : 1, c.lits = e->ival ? 1 : 0, c.slots = e->ival ? 2 : 1;
+      return c;
+    case EK_KEY_HASH: {
+      ExprCost before = e->l ? expr_cost(e->l, schema) : ExprCost{};
+      ExprCost part;
+      if (expr_type(e->r, schema) == QE_TYPE_UTF8) part.insns = 1, part.slots = 1;
+      else part = expr_cost(e->r, schema);
+      c.insns = before.insns + part.insns + (e->l ? 4 : 3);
+      c.lits = before.lits + part.lits + 1;
+      c.slots = std::max(e->l ? std::max(before.slots, 2) : 1, 1 + part.slots);
+      return c;
+    }
+    default: break;
+  }
+  if (e->to_f64) {
+    c = expr_cost(e->l, schema);
+    c.insns += 1;
+    return c;
+  }
+  if (expr_type(e->l, schema) == QE_TYPE_UTF8) {  // one comparison instruction; a literal operand is (address, length)
+    c.insns = 1, c.lits = 2, c.slots = 1;
+    return c;
+  }
+  const ExprCost a = expr_cost(e->l, schema), b = expr_cost(e->r, schema);
+  c.insns = a.insns + b.insns + 2;  // the operation, and a swap when the right operand goes first
+  c.lits = a.lits + b.lits;
+  c.slots = a.slots == b.slots ? a.slots + 1 : std::max(a.slots, b.slots);
+  return c;
+}
+
 bool Compiler::fits(const ExprPtr &e) const {
-  int nodes = count_nodes(e);
-  if (n_insn + 2 * nodes + 2 > VM_MAX_INSN) return false;
-  if (n_lits + 2 * nodes > VM_MAX_LITS) return false;
+  const ExprCost c = expr_cost(e, schema);
+  if (n_insn + c.insns + 1 > VM_MAX_INSN) return false;
+  if (n_lits + c.lits > VM_MAX_LITS) return false;
   std::map<int, int> seen;
-  collect_cols(e, seen);
+  expr_columns(e, seen);
   int extra = 0;
   for (auto &kv : seen)
     if (!colmap.count(kv.first)) ++extra;
@@ -564,14 +597,7 @@ int Compiler::lit_slot(uint64_t bits) {
 }
 
 // Registers (stack slots) an expression needs when its deeper operand is evaluated first.
-int Compiler::need(const ExprPtr &e) const {
-  if (e->kind != EK_BINARY) return 1;
-  if (e->to_f64) return need(e->l);
-  int lt = expr_type(e->l, schema);
-  if (lt == QE_TYPE_UTF8) return 1;
-  int a = need(e->l), b = need(e->r);
-  return a == b ? a + 1 : (a > b ? a : b);
-}
+int Compiler::need(const ExprPtr &e) const { return expr_cost(e, schema).slots; }
 
 static uint32_t math_op(int op, int type) {
   int base = type == QE_TYPE_INT32 ? OP_ADD_I32 : type == QE_TYPE_INT64 ? OP_ADD_I64 : OP_ADD_F64;
@@ -632,7 +658,17 @@ void Compiler::emit(const ExprPtr &e, int depth) {
     }
     case EK_LITERAL: {
       if (e->type == QE_TYPE_UTF8) fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "Physical type `Utf8` is not supported in a computed expression.");
-      if (!e->valid) fail(QE_ERR_SCALAR_TO_ARRAY, "Couldn't convert Scalar value `null` to array.");
+      if (!e->valid) {
+        // A null scalar as an operand of arithmetic or of a comparison makes the whole result null (the reference's
+        // scalar arms, physical_expressions.rs:194-203 and :258-268, hand the scalar's `None` to arrow2); the one way this machine makes a
+        // null out of nothing is an integer division by zero, which leaves zero bits with the validity cleared.
+        if (depth + 1 >= VM_MAX_DEPTH) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression is nested too deeply.");
+        const uint32_t zero = (uint32_t)lit_slot(0);
+        push_insn(OP_PUSH_LIT, depth, zero);
+        push_insn(OP_PUSH_LIT, depth + 1, zero);
+        push_insn(OP_DIV_I64, depth + 2, 0);
+        return;
+      }
       uint64_t bits;
       if (e->type == QE_TYPE_FLOAT64) std::memcpy(&bits, &e->fval, 8);
       else bits = (uint64_t)e->ival;
@@ -702,8 +738,13 @@ void Compiler::emit(const ExprPtr &e, int depth) {
     push_insn(ne ? OP_UTF8_NE_LIT : OP_UTF8_EQ_LIT, depth, (uint32_t)col_slot(col->index) | ((uint32_t)li << 8));
     return;
   }
-  int na = need(e->l), nb = need(e->r);
   int op = e->op;
+  // AND / OR broadcast a scalar operand into an array first, which a null scalar cannot be (columnar_value.rs:33);
+  // arithmetic and comparisons hand the scalar to arrow2's *_scalar kernels, where a null scalar gives an all-null result
+  if (is_bool(op))
+    for (const ExprPtr &x : {e->l, e->r})
+      if (x->kind == EK_LITERAL && !x->valid) fail(QE_ERR_SCALAR_TO_ARRAY, "Couldn't convert Scalar value `null` to array.");
+  int na = need(e->l), nb = need(e->r);
   bool swapped = nb > na;
   if (swapped) {
     emit(e->r, depth);

@@ -184,6 +184,15 @@ bool expr_nullable(const ExprPtr &e, const Schema &schema);
 ExprPtr expr_normalize(const ExprPtr &e, uint32_t flags);
 // Replace Column(i) by outputs[i].
 ExprPtr expr_substitute(const ExprPtr &e, const std::vector<ExprPtr> &outputs);
+// What a (normalised) expression takes of one kernel's program: instructions without the closing
+// OP_END, literal slots (an upper bound: equal literals share one), stack slots when the deeper
+// operand of every node is evaluated first.
+struct ExprCost {
+  int insns = 0, lits = 0, slots = 0;
+};
+ExprCost expr_cost(const ExprPtr &e, const Schema &schema);
+// Batch columns the expression reads.
+void expr_columns(const ExprPtr &e, std::map<int, int> &seen);
 
 // ----------------------------------------------------- expression compiler
 struct Compiler {
@@ -198,7 +207,7 @@ struct Compiler {
   uint32_t all_cache_mask = 0;         // ... by every expression added so far
   std::vector<BufferPtr> keepalive;    // device copies of utf8 literals
   Compiler(Context *c, const Batch *b);
-  // Space check before adding an expression: worst-case instruction / literal / column needs.
+  // Space check before adding an expression: instruction / literal / column needs.
   bool fits(const ExprPtr &e) const;
   // Emits code ending in OP_END, returns the start pc.
   uint32_t add(const ExprPtr &e);

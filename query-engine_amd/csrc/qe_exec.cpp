@@ -280,6 +280,83 @@ static bool mentions_column_of_type(const ExprPtr &e, const Batch &in, int type)
 
 static Batch run_pipeline_typed(Context *ctx, const Batch &in, const std::vector<ExprPtr> &outputs_raw, const ExprPtr &pred_raw);
 
+// ---- expressions larger than one kernel's program
+// A kernel evaluates its expressions on a stack of VM_MAX_DEPTH slots, out of a program of VM_MAX_INSN
+// instructions, VM_MAX_LITS literals and VM_MAX_COLS columns.  The reference evaluates a tree of any
+// size, one array per node (physical_expressions.rs:243-268).  A tree that exceeds a kernel is cut:
+// subtrees are evaluated by a projection launch of their own into temporary columns appended to the
+// batch, and the tree reads those columns instead.  The limits per expression leave room for a
+// predicate and one output in the same program.
+constexpr int FIT_INSNS = 40, FIT_LITS = 10, FIT_COLS = 8;
+
+struct ExprFitter {
+  Context *ctx;
+  Batch &in;      // grows by the temporary columns
+  Schema schema;  // of `in`
+  int temporaries = 0;
+
+  static bool leaf(const ExprPtr &e) { return e->kind != EK_BINARY; }
+  bool over(const ExprPtr &e) const {
+    const ExprCost c = expr_cost(e, schema);
+    if (c.insns > FIT_INSNS || c.lits > FIT_LITS || c.slots > VM_MAX_DEPTH) return true;
+    std::map<int, int> seen;
+    expr_columns(e, seen);
+    return (int)seen.size() > FIT_COLS;
+  }
+  ExprPtr materialise(const ExprPtr &e) {
+    Batch t = run_pipeline_typed(ctx, in, {e}, nullptr);
+    in.cols.push_back(t.cols[0]);
+    schema = schema_of(in);
+    ++temporaries;
+    return make_column((int)in.cols.size() - 1);
+  }
+  // The expression with every subtree small enough for one kernel (expects a normalised, type-checked tree).
+  ExprPtr shrink(const ExprPtr &e) {
+    if (leaf(e)) return e;
+    if (e->to_f64 || !e->r) {
+      auto n = std::make_shared<Expr>(*e);
+      n->l = shrink(e->l);
+      return n;
+    }
+    if (expr_type(e->l, schema) == QE_TYPE_UTF8) return e;  // one comparison instruction
+    ExprPtr l = shrink(e->l), r = shrink(e->r);
+    auto node = [&] {
+      auto n = std::make_shared<Expr>(*e);
+      n->l = l;
+      n->r = r;
+      return ExprPtr(n);
+    };
+    ExprPtr cur = node();
+    while (over(cur) && !(leaf(l) && leaf(r))) {
+      // the costlier operand becomes a column
+      const bool left = leaf(r) || (!leaf(l) && expr_cost(l, schema).insns >= expr_cost(r, schema).insns);
+      if (left) l = materialise(l);
+      else r = materialise(r);
+      cur = node();
+    }
+    return cur;
+  }
+  // Expressions that share one program (an aggregate's predicate, keys and accumulator inputs): the largest
+  // become columns until all of them fit.  An expression listed twice is compiled twice.
+  void fit_together(const std::vector<ExprPtr *> &exprs, int reserve_insns, int reserve_lits) {
+    for (;;) {
+      int insns = reserve_insns, lits = reserve_lits, worst_insns = 0;
+      std::map<int, int> seen;
+      ExprPtr *worst = nullptr;
+      for (ExprPtr *p : exprs) {
+        if (!*p) continue;
+        const ExprCost c = expr_cost(*p, schema);
+        insns += c.insns + 2;
+        lits += c.lits;
+        expr_columns(*p, seen);
+        if (!leaf(*p) && c.insns > worst_insns) worst = p, worst_insns = c.insns;
+      }
+      if (!worst || (insns <= VM_MAX_INSN && lits <= VM_MAX_LITS && (int)seen.size() <= VM_MAX_COLS)) return;
+      *worst = materialise(*worst);
+    }
+  }
+};
+
 // Timestamp columns only ever pass through (the reference's ColumnExpression would not even
 // hand them out, physical_expressions.rs:37-60): they travel as the 64-bit integers they are
 // and get their type back on the way out.
@@ -306,7 +383,7 @@ static Batch run_pipeline(Context *ctx, const Batch &in, const std::vector<ExprP
 }
 
 static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::vector<ExprPtr> &outputs_raw, const ExprPtr &pred_raw) {
-  const Batch in = without_redundant_validity(in_raw);
+  Batch in = without_redundant_validity(in_raw);
   ctx->bind();
   const int64_t n = in.rows;
   Schema schema = schema_of(in);
@@ -325,6 +402,12 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
   for (auto &e : outs)
     if (e->kind == EK_LITERAL && !e->valid)
       fail(QE_ERR_SCALAR_TO_ARRAY, "Couldn't convert Scalar value `null` to array.");  // columnar_value.rs:33
+  {
+    ExprFitter fitter{ctx, in, schema};
+    for (auto &e : outs) e = fitter.shrink(e);
+    if (pred) pred = fitter.shrink(pred);
+    if (fitter.temporaries) schema = fitter.schema;
+  }
 
   Batch out;
   out.ctx = ctx;
@@ -849,7 +932,7 @@ struct AggState {
   // Folds one batch in.  `outputs` (may be empty = the batch's columns) are the expressions the
   // group / aggregate expressions' column indices refer to; `pred` selects rows.
   void update(const Batch &in_raw, const std::vector<ExprPtr> &outputs, const ExprPtr &pred) {
-    const Batch in = strict ? in_raw : without_redundant_validity(in_raw);
+    Batch in = strict ? in_raw : without_redundant_validity(in_raw);
     ctx->bind();
     ensure_counters(ctx);
     std::vector<ExprPtr> src_outs = outputs;
@@ -870,6 +953,26 @@ struct AggState {
       a2_second.push_back(second);
     }
     Schema schema = schema_of(in);
+    ExprPtr pred_n = pred ? expr_normalize(pred, ctx->flags) : nullptr;
+    {
+      // predicate, keys and accumulator inputs share one program: whatever exceeds it is evaluated beforehand
+      std::vector<ExprPtr *> all;
+      if (pred_n) all.push_back(&pred_n);
+      for (auto &g : g2) all.push_back(&g);
+      for (auto &a : a2)
+        if (a.input) {
+          all.push_back(&a.input);
+          if (a.kind == QE_AGG_AVG) all.push_back(&a.input);  // its sum and its count each evaluate the input
+        }
+      for (ExprPtr *p : all) {
+        *p = expr_normalize(*p, ctx->flags);
+        (void)expr_type(*p, schema);
+      }
+      ExprFitter fitter{ctx, in, schema};
+      for (ExprPtr *p : all) *p = fitter.shrink(*p);
+      fitter.fit_together(all, 24 + (int)a2.size(), 4);
+      if (fitter.temporaries) schema = fitter.schema;
+    }
     AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode, row_base);
     key_sources.resize(bspec.key_gathers.size());
     for (size_t i = 0; i < bspec.key_gathers.size(); ++i) key_sources[i].push_back(Utf8KeySource{in.cols[bspec.key_gathers[i].col], row_base});
@@ -921,7 +1024,7 @@ struct AggState {
     if (in.rows == 0) return;
     Compiler comp(ctx, &in);
     AggArgs args{};
-    lower_aggregate(comp, schema, pred ? expr_normalize(pred, ctx->flags) : nullptr, bspec, spec, args);
+    lower_aggregate(comp, schema, pred_n, bspec, spec, args);
     args.table = table;
     args.n_rows = in.rows;
     args.lds_cap = aggregate_lds_slots(args.n_accs, ctx->dev, cap_hint);

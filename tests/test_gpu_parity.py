@@ -110,6 +110,19 @@ def test_evaluate_contract(qe, ctx):
         want = mk(orc, spec).evaluate(chunk)
         assert got.is_scalar and want.is_scalar
         assert got.scalar == val and want.scalar.value == val, spec
+    # a null scalar (here: a folded division by zero) next to an array: arithmetic and comparisons give an
+    # all-null array, AND / OR cannot broadcast it
+    null_i32, null_i64 = ("div", ("i32", 1), ("i32", 0)), ("mod", ("i64", 1), ("i64", 0))
+    for spec in (("add", C(1), null_i32), ("mul", null_i64, C(3)), ("gt", C(1), null_i32), ("eq", null_i64, C(2)),
+                 ("and", ("lt", C(3), null_i64), C(7)), ("add", ("mul", C(0), null_i32), C(1))):
+        want = mk(orc, spec).evaluate(chunk)
+        got = mk(qe, spec).evaluate(batch)
+        assert want.array.validity is not None and not want.array.validity.any(), spec
+        assert_column_equal(got.array.columns()[0], want.array, what=f"null scalar {spec}")
+    for m, err in ((qe, qe.QeError), (orc, orc.OracleError)):
+        with pytest.raises(err) as e:
+            mk(m, ("and", C(6), ("gt", ("i32", 1), null_i32))).evaluate(batch if m is qe else chunk)
+        assert e.value.name == "ScalarToArrayError"
     # column pass-through is zero copy and typed
     got = qe.ColumnExpression(2).evaluate(batch)
     assert_column_equal(got.array.columns()[0], cols[2])
