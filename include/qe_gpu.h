@@ -282,10 +282,13 @@ qe_status qe_plan_selection(qe_plan *child, qe_expr *predicate, qe_plan **out);
  * (physical_plan/mod.rs:258-272).  `mode` is QE_AGG_MODE_*;
  * `group_capacity_hint` (0 = default) sizes the global group table; the table
  * grows and the aggregation is re-run when the hint proves too small.  Group
- * keys: Int32 / Int64 / Boolean expressions packed into 64 bits, or one Utf8
- * column; tuples beyond that (strings next to other keys, several strings, more
- * than 64 bits) must be plain columns and are identified by a 64-bit hash of the
- * tuple - the reference identifies every group by hash (physical_plan/mod.rs:317-358). */
+ * keys: up to four Int32 / Int64 / Boolean expressions packed into 64 bits, or
+ * one Utf8 column; tuples beyond that (strings next to other keys, several
+ * strings, more than 64 bits, up to twelve expressions) are identified by a
+ * 64-bit hash of the tuple - the reference identifies every group by hash
+ * (physical_plan/mod.rs:317-358) - and computed keys among them are evaluated
+ * into columns first.  At most sixteen accumulators per aggregate (AVG and a
+ * nullable input take two). */
 qe_status qe_plan_aggregate(qe_plan *child, qe_expr *const *group_exprs, int32_t n_group_exprs,
                             qe_agg_expr *const *agg_exprs, int32_t n_agg_exprs, int32_t mode,
                             int64_t group_capacity_hint, qe_plan **out);

@@ -586,33 +586,42 @@ static ExprPtr make_to_f64(const ExprPtr &e) {
 
 static bool numeric(int t) { return t == QE_TYPE_INT32 || t == QE_TYPE_INT64 || t == QE_TYPE_FLOAT64; }
 
+// Group key tuples that do not fit the 64-bit packed key - a string next to other keys, several strings, more
+// than 64 bits of integers, more fields than the packed key has - are identified by a 64-bit hash of the tuple.
+constexpr int MAX_HASHED_KEYS = 12;
+static bool key_tuple_hashed(const std::vector<int> &types) {
+  int total_bits = 0, strings = 0;
+  for (int t : types) {
+    strings += t == QE_TYPE_UTF8;
+    total_bits += t == QE_TYPE_INT32 ? 32 : t == QE_TYPE_INT64 ? 64 : t == QE_TYPE_BOOLEAN ? 1 : t == QE_TYPE_UTF8 ? 64 : 0;
+  }
+  return types.size() > 1 && (strings > 0 || total_bits > 64 || (int)types.size() > VM_MAX_KEYS);
+}
+
 static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::vector<ExprPtr> &groups,
                               const std::vector<AggExpr> &aggs, const std::vector<ExprPtr> &aggs_second, int mode,
                               int64_t row_base = 0) {
   AggSpec spec;
   int shift = 0;
-  if ((int)groups.size() > VM_MAX_KEYS) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many group expressions.");
-  // Keys that do not fit the 64-bit packed key - a string next to other keys, several strings, more than 64
-  // bits of integers - are identified by a 64-bit hash of the tuple, as the reference identifies every group
-  // (physical_plan/mod.rs:317-358 sums per-column hashes); the key columns of the output are gathered from a
-  // representative row of each group, so every key must be a plain column.
+  if ((int)groups.size() > MAX_HASHED_KEYS) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many group expressions.");
+  // A hashed key tuple identifies groups as the reference identifies every group (physical_plan/mod.rs:317-358
+  // sums per-column hashes); the key columns of the output are gathered from a representative row of each group,
+  // so every key is a plain column here (AggState::update evaluates computed keys into columns beforehand).
   {
-    int total_bits = 0, strings = 0;
     std::vector<ExprPtr> norm;
+    std::vector<int> key_types;
     for (auto &g : groups) {
       norm.push_back(expr_normalize(g, flags));
-      const int t = expr_type(norm.back(), schema);
-      strings += t == QE_TYPE_UTF8;
-      total_bits += t == QE_TYPE_INT32 ? 32 : t == QE_TYPE_INT64 ? 64 : t == QE_TYPE_BOOLEAN ? 1 : t == QE_TYPE_UTF8 ? 64 : 0;
+      key_types.push_back(expr_type(norm.back(), schema));
     }
-    if (groups.size() > 1 && (strings > 0 || total_bits > 64)) {
+    if (key_tuple_hashed(key_types)) {
       ExprPtr h;
       for (auto &e : norm) {
         const int t = expr_type(e, schema);
         if (!(t == QE_TYPE_INT32 || t == QE_TYPE_INT64 || t == QE_TYPE_BOOLEAN || t == QE_TYPE_UTF8))
           fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, std::string("Physical type `") + type_name(t) + "` is not supported as a group key.");
         if (e->kind != EK_COLUMN)
-          fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "Group keys wider than 64 bits in all (or including a Utf8 column) must be plain columns.");
+          fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "Group keys identified by a hash of the tuple must be plain columns.");
         h = make_key_hash(h, e);
       }
       VmKey k{};
@@ -738,6 +747,8 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
         fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression `aggregate` is not supported.");
     }
   }
+  if (spec.outs.size() > sizeof(FinalizeArgs::outs) / sizeof(FinOut))
+    fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many output columns for one aggregate.");
   return spec;
 }
 
@@ -970,7 +981,12 @@ struct AggState {
       }
       ExprFitter fitter{ctx, in, schema};
       for (ExprPtr *p : all) *p = fitter.shrink(*p);
-      fitter.fit_together(all, 24 + (int)a2.size(), 4);
+      std::vector<int> key_types;
+      for (auto &g : g2) key_types.push_back(expr_type(g, fitter.schema));
+      if (key_tuple_hashed(key_types))  // key columns are gathered from a representative row: computed keys become columns
+        for (auto &g : g2)
+          if (g->kind != EK_COLUMN) g = fitter.materialise(g);
+      fitter.fit_together(all, 12 + 5 * (int)g2.size() + (int)a2.size(), 4);
       if (fitter.temporaries) schema = fitter.schema;
     }
     AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode, row_base);

@@ -437,12 +437,12 @@ def test_utf8_group_key(qe, ctx):
     want = _by_key(list(build2(orc, orc.ScanExec([orc.Chunk(keyed)])).execute())[0].arrays, True)
     got = _by_key(list(build2(qe, qe.ScanExec(ctx, [gpu_batch(qe, ctx, keyed)])).execute())[0].columns(), False)
     assert got == want
-    with pytest.raises(qe.QeError) as e:
-        # next to a string key every key must be a plain column (the output keys are gathered from the source)
-        computed = qe.AddExpression(qe.ColumnExpression(COL["id"]), qe.LiteralIntegerExpression(1))
-        list(qe.AggregateExec([qe.ScanExec(ctx, [gpu_batch(qe, ctx, arrays)])], [qe.ColumnExpression(ci), computed],
-                              [qe.MaxExpression(qe.ColumnExpression(si))]).execute())
-    assert e.value.name == "PhysicalTypeNotSuported"
+    # a computed key next to a string key: evaluated into a column first (the output keys are gathered from the source)
+    def build3(m, scan):
+        return m.AggregateExec([scan], [mk(m, C(ci)), mk(m, ("mod", C(COL["id"]), ("i32", 3)))], [mk(m, ("max", C(si))), mk(m, ("count", None))])
+    want = _rows_by_key(list(build3(orc, orc.ScanExec([orc.Chunk(arrays)])).execute())[0].arrays, 2, True)
+    got = _rows_by_key(list(build3(qe, qe.ScanExec(ctx, [gpu_batch(qe, ctx, arrays)])).execute())[0].columns(), 2, False)
+    assert got == want and len(got) > 120
 
 
 def _rows_by_key(cols, n_keys, oracle):
@@ -470,9 +470,14 @@ def test_composite_group_keys(qe, ctx):
                 orc.Array(orc.FLOAT64, r.uniform(-10, 10, n), r.random(n) > 0.1), orc.Array(orc.INT64, r.integers(-100, 100, n))]
     aggs = [("sum", C(5)), ("count", C(5)), ("count", None), ("min", C(5)), ("max", C(6)), ("avg", C(6))]
     parts = [table(n, 1), table(7, 2), table(n // 2, 3)]
-    for keys in ([0, 2], [0, 1], [3, 6], [1, 4, 2, 3], [0, 3]):
+    computed = [  # more fields than the packed key has; computed keys (nullable ones too) inside a hashed tuple
+        [C(2), C(4), ("mod", C(6), ("i64", 5)), ("lt", C(6), ("i64", 0)), ("mod", C(2), ("i32", 2))],
+        [("mod", C(6), ("i64", 3)), C(0)],
+        [C(2), C(4), C(6), ("div", C(6), C(6)), C(1), ("gt", C(5), ("f64", 0.0)), ("add", C(3), C(6))],
+    ]
+    for keys in [[C(k) for k in ks] for ks in ([0, 2], [0, 1], [3, 6], [1, 4, 2, 3], [0, 3])] + computed:
         def build(m, scan):
-            return m.AggregateExec([scan], [mk(m, C(k)) for k in keys], [mk(m, a) for a in aggs])
+            return m.AggregateExec([scan], [mk(m, k) for k in keys], [mk(m, a) for a in aggs])
         want = _rows_by_key(list(build(orc, orc.ScanExec([orc.Chunk(p) for p in parts])).execute())[0].arrays, len(keys), True)
         got = _rows_by_key(list(build(qe, qe.ScanExec(ctx, [gpu_batch(qe, ctx, p) for p in parts])).execute())[0].columns(), len(keys), False)
         assert set(got) == set(want), keys
