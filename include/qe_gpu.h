@@ -287,8 +287,8 @@ qe_status qe_plan_selection(qe_plan *child, qe_expr *predicate, qe_plan **out);
  * strings, more than 64 bits, up to twelve expressions) are identified by a
  * 64-bit hash of the tuple - the reference identifies every group by hash
  * (physical_plan/mod.rs:317-358) - and computed keys among them are evaluated
- * into columns first.  At most sixteen accumulators per aggregate (AVG and a
- * nullable input take two). */
+ * into columns first.  Any number of aggregates: lists beyond one kernel's
+ * sixteen accumulators are split over several kernels and joined by group. */
 qe_status qe_plan_aggregate(qe_plan *child, qe_expr *const *group_exprs, int32_t n_group_exprs,
                             qe_agg_expr *const *agg_exprs, int32_t n_agg_exprs, int32_t mode,
                             int64_t group_capacity_hint, qe_plan **out);

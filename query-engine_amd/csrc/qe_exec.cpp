@@ -10,6 +10,7 @@
 #include <cstring>
 #include <functional>
 #include <sstream>
+#include <unordered_map>
 
 #include "qe_core.h"
 #include "qe_jit.h"
@@ -600,7 +601,7 @@ static bool key_tuple_hashed(const std::vector<int> &types) {
 
 static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::vector<ExprPtr> &groups,
                               const std::vector<AggExpr> &aggs, const std::vector<ExprPtr> &aggs_second, int mode,
-                              int64_t row_base = 0) {
+                              int64_t row_base = 0, bool emit_row_number = false) {
   AggSpec spec;
   int shift = 0;
   if ((int)groups.size() > MAX_HASHED_KEYS) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many group expressions.");
@@ -746,6 +747,11 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
       default:
         fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression `aggregate` is not supported.");
     }
+  }
+  if (emit_row_number) {
+    // the smallest row number of the group, as a last output column: it names the group in every part of a split aggregation
+    const int a = add_acc(spec, ACC_MIN, QE_TYPE_INT64, false, make_rowid(row_base));
+    spec.outs.push_back(fin(FIN_ACC_ORD, QE_TYPE_INT64, a, a, CNT_ROWS, NULL_NEVER));
   }
   if (spec.outs.size() > sizeof(FinalizeArgs::outs) / sizeof(FinOut))
     fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many output columns for one aggregate.");
@@ -924,6 +930,14 @@ struct AggState {
   int64_t row_base = 0;
   int deferred_finishes = 0;
   BufferPtr deferred_block;  // output block of the deferred mode, cleared by the table's init launch
+  // More aggregates than one kernel has accumulators for: the list is split, every part aggregates the same rows
+  // by the same keys plus a hidden MIN(row number), and the parts' outputs are put side by side by that number
+  // (the reference keeps one accumulator object per group and aggregate, physical_plan/mod.rs:340-372: no limit).
+  std::vector<std::unique_ptr<AggState>> parts;
+  bool emit_row_number = false;  // this is such a part
+
+  static int acc_weight(const AggExpr &a) { return a.kind == QE_AGG_AVG ? 2 : 1; }  // accumulators an aggregate may take
+  static constexpr int PART_ACC_BUDGET = VM_MAX_ACCS - 2;                           // the row number, and one to spare
 
   // Fresh table for about `hint` groups.
   void start(int64_t hint) {
@@ -932,6 +946,26 @@ struct AggState {
     cap = 1024;
     while (cap < (uint64_t)hint * 2) cap <<= 1;
     if (cap > (1ull << 30)) fail(QE_ERR_AGG_CAPACITY, "group table would exceed 2^30 slots");
+    parts.clear();
+    int weight = 0;
+    for (auto &a : aggs) weight += acc_weight(a);
+    if (!emit_row_number && weight > PART_ACC_BUDGET) {
+      for (size_t i = 0; i < aggs.size();) {
+        auto p = std::make_unique<AggState>();
+        p->ctx = ctx;
+        p->strict = strict;
+        p->groups = groups;
+        p->mode = mode;
+        p->cap_hint = cap_hint;
+        p->emit_row_number = true;
+        for (int w = 0; i < aggs.size() && (w == 0 || w + acc_weight(aggs[i]) <= PART_ACC_BUDGET); ++i) {
+          w += acc_weight(aggs[i]);
+          p->aggs.push_back(aggs[i]);
+        }
+        p->start(hint);
+        parts.push_back(std::move(p));
+      }
+    }
     have_table = false;
     spec = AggSpec();
     table = AggTable{};
@@ -943,6 +977,10 @@ struct AggState {
   // Folds one batch in.  `outputs` (may be empty = the batch's columns) are the expressions the
   // group / aggregate expressions' column indices refer to; `pred` selects rows.
   void update(const Batch &in_raw, const std::vector<ExprPtr> &outputs, const ExprPtr &pred) {
+    if (!parts.empty()) {
+      for (auto &p : parts) p->update(in_raw, outputs, pred);
+      return;
+    }
     Batch in = strict ? in_raw : without_redundant_validity(in_raw);
     ctx->bind();
     ensure_counters(ctx);
@@ -989,7 +1027,7 @@ struct AggState {
       fitter.fit_together(all, 12 + 5 * (int)g2.size() + (int)a2.size(), 4);
       if (fitter.temporaries) schema = fitter.schema;
     }
-    AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode, row_base);
+    AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode, row_base, emit_row_number);
     key_sources.resize(bspec.key_gathers.size());
     for (size_t i = 0; i < bspec.key_gathers.size(); ++i) key_sources[i].push_back(Utf8KeySource{in.cols[bspec.key_gathers[i].col], row_base});
     row_base += in.rows;
@@ -1070,7 +1108,7 @@ struct AggState {
     return total;
   }
   bool deferred_wanted() const {
-    return table.cap + 1 <= (1u << 16) && (ctx->flags & QE_FLAG_DEFERRED_GROUP_COUNT) && spec.key_gathers.empty();
+    return table.cap + 1 <= (1u << 16) && (ctx->flags & QE_FLAG_DEFERRED_GROUP_COUNT) && spec.key_gathers.empty() && !emit_row_number;
   }
 
   bool finish_deferred(Batch &result) {
@@ -1117,8 +1155,57 @@ struct AggState {
   }
 
   // The output batch.  False when the table overflowed: the caller starts over with a larger one.
+  // The parts' outputs side by side, in the first part's row order.
+  bool finish_parts(Batch &result) {
+    std::vector<Batch> rs(parts.size());
+    for (size_t j = 0; j < parts.size(); ++j)
+      if (!parts[j]->finish(rs[j])) return false;
+    const int64_t n = rs[0].rows;
+    auto row_numbers = [&](const Batch &b) {
+      std::vector<int64_t> ids((size_t)n);
+      QE_HIP(hipMemcpyAsync(ids.data(), b.cols.back().values_ptr(), (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+      ctx->sync();
+      return ids;
+    };
+    result = Batch();
+    result.ctx = ctx;
+    result.rows = n;
+    for (size_t c = 0; c + 1 < rs[0].cols.size(); ++c) result.cols.push_back(rs[0].cols[c]);
+    std::unordered_map<int64_t, int64_t> at;
+    const std::vector<int64_t> first = row_numbers(rs[0]);
+    for (int64_t i = 0; i < n; ++i) at[first[(size_t)i]] = i;
+    for (size_t j = 1; j < parts.size(); ++j) {
+      if (rs[j].rows != n) fail(QE_ERR_INTERNAL, "the parts of a split aggregation found different groups");
+      const std::vector<int64_t> ids = row_numbers(rs[j]);
+      std::vector<int64_t> perm((size_t)n);
+      for (int64_t i = 0; i < n; ++i) {
+        auto it = at.find(ids[(size_t)i]);
+        if (it == at.end()) fail(QE_ERR_INTERNAL, "the parts of a split aggregation found different groups");
+        perm[(size_t)it->second] = i;
+      }
+      BufferPtr dev_perm = device_buffer(ctx, (size_t)n * 8 + 16);
+      QE_HIP(hipMemcpyAsync(dev_perm->ptr, perm.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+      ctx->sync();  // `perm` (host) has been read
+      for (size_t c = groups.size(); c + 1 < rs[j].cols.size(); ++c) {
+        const Column &src = rs[j].cols[c];
+        Column out = fixed_gather_rows(ctx, src.type, {Utf8KeySource{src, 0}}, (const int64_t *)dev_perm->ptr, n);
+        if (src.validity) {
+          Column bits;
+          bits.type = QE_TYPE_BOOLEAN;
+          bits.length = n;
+          bits.values = src.validity;
+          out.validity = fixed_gather_rows(ctx, QE_TYPE_BOOLEAN, {Utf8KeySource{bits, 0}}, (const int64_t *)dev_perm->ptr, n).values;
+          out.null_count = -1;
+        }
+        result.cols.push_back(out);
+      }
+    }
+    return true;
+  }
+
   bool finish(Batch &result) {
     ctx->bind();
+    if (!parts.empty()) return finish_parts(result);
     // empty input: `iter.next().ok_or(Error::EmptyHashmapForAggregate)` (physical_plan/mod.rs:377)
     if (!have_table) fail(QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE, "The hashmap for aggregation is empty.");
     // Small tables: the output columns are sized for every slot and the finalize pass is queued

@@ -356,11 +356,14 @@ def test_aggregate_batches_filter_growth_and_errors(qe, ctx):
 
 def test_partial_final_aggregate(qe, ctx):
     """Two shards aggregated in PARTIAL mode and merged in FINAL mode equal the single aggregate."""
-    cols = agg_columns(60_000, 700, seed=21)
+    aggs = [("max", C(2)), ("min", C(3)), ("sum", C(2)), ("sum", C(4)), ("count", C(2)), ("count", None), ("avg", C(2)), ("avg", C(3))]
+    check_partial_final(qe, ctx, agg_columns(60_000, 700, seed=21), aggs)
+
+
+def check_partial_final(qe, ctx, cols, aggs):
     half = 31_111
     shards = [[orc.Array(a.type, a.values[s], None if a.validity is None else a.validity[s]) for a in cols] for s in (slice(0, half), slice(half, None))]
     groups = [C(0)]
-    aggs = [("max", C(2)), ("min", C(3)), ("sum", C(2)), ("sum", C(4)), ("count", C(2)), ("count", None), ("avg", C(2)), ("avg", C(3))]
     partials = []
     for sh in shards:
         plan = qe.AggregateExec([qe.ScanExec(ctx, [gpu_batch(qe, ctx, sh)])], [mk(qe, g) for g in groups], [mk(qe, a) for a in aggs], mode=qe.AGG_MODE_PARTIAL)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from test_gpu_parity import C, agg_columns, make_columns, mk, rng, run_agg, run_both
+from test_gpu_parity import C, agg_columns, check_partial_final, make_columns, mk, rng, run_agg, run_both
 from util import assert_column_equal, gpu_batch
 
 pytestmark = pytest.mark.gpu
@@ -211,3 +211,38 @@ def random_f64_over_agg_columns(r, depth):
     if not has_column(l) and not has_column(rr):
         l = C(5)
     return (op, l, rr)
+
+
+def test_more_aggregates_than_one_kernel_accumulates(qe, ctx):
+    """Forty aggregates (a kernel carries sixteen accumulators): the list is split, the parts' outputs are put side
+    by side.  Nullable inputs, computed inputs, a predicate, several batches, packed and hashed keys, no key at all."""
+    acols = [agg_columns(n, 40, seed=s, key_dtype=np.int32) for n, s in ((30_000, 41), (5, 42), (9000, 43))]
+    v, iv, i32v, f = C(2), C(3), C(4), C(5)
+    kinds = ["sum", "max", "min", "avg", "count"]
+    inputs = [v, iv, i32v, f, ("mul", v, f), ("add", f, ("f64", 1.5)), ("sub", iv, ("i64", 7)), ("mul", i32v, ("i32", 3))]
+    many = [(kinds[i % 5], inputs[(i // 5 + i) % 8]) for i in range(39)] + [("count", None)]
+    run_agg(qe, ctx, acols, [C(0), C(1)], many, pred=("gt", f, ("f64", 0.25)), what="forty aggregates, two packed keys")
+    run_agg(qe, ctx, acols, [], many, what="forty aggregates, one global group")
+    run_agg(qe, ctx, acols, [C(0), C(1), ("mod", C(4), ("i32", 3)), ("gt", f, ("f64", 0.5)), ("mod", C(1), ("i32", 2))], many[:25],
+            what="twenty-five aggregates, five keys (hashed tuple)")
+    run_agg(qe, ctx, [agg_columns(150_000, 100_000, seed=44, nulls=False)], [C(0)], many[:20], hint=64, what="split aggregation, table growth")
+    # PARTIAL per shard -> FINAL, both split (an AVG travels as a sum and a count)
+    check_partial_final(qe, ctx, agg_columns(60_000, 700, seed=45), many[:30])
+    # the streaming accumulator protocol: batches fed one by one to a split state, a running result in between
+    exact = [(k, x) for k, x in many if k in ("max", "min", "count")][:20]
+    batches = [gpu_batch(qe, ctx, a) for a in acols]
+    state = qe.AggregationState(ctx, [mk(qe, C(0))], [mk(qe, a) for a in exact], group_capacity_hint=8)
+    state.accumulate(batches[0])
+    assert state.final_value().num_rows == 40
+    for b in batches[1:]:
+        state.accumulate(b)
+    got = state.final_value().columns()
+    state.close()
+    want = list(orc.AggregateExec([orc.ScanExec([orc.Chunk(a) for a in acols])], [mk(orc, C(0))], [mk(orc, a) for a in exact]).execute())[0].arrays
+    og, ow = np.argsort(np.asarray(got[0].values)), np.argsort(want[0].values)
+    assert len(got) == len(want) == 21
+    for g, w in zip(got, want):
+        wv = np.ones(len(w), np.bool_) if w.validity is None else w.validity
+        gv = np.ones(len(w), np.bool_) if g.validity is None else np.asarray(g.validity, dtype=bool)
+        assert np.array_equal(gv[og], wv[ow])
+        assert np.array_equal(np.asarray(g.values)[og][wv[ow]], w.values[ow][wv[ow]])
