@@ -309,6 +309,38 @@ std::string expr_to_string(const ExprPtr &e) {
   return o.str();
 }
 
+// expr_to_string follows the reference's Display, which prints a column and an integer literal alike ("#2")
+// and no parentheses; this one is shared by two expressions exactly when they are the same tree.
+std::string expr_identity(const ExprPtr &e) {
+  if (!e) return "-";
+  std::ostringstream o;
+  switch (e->kind) {
+    case EK_COLUMN: o << "c" << e->index; break;
+    case EK_LITERAL:
+      o << "l" << e->type << ":";
+      if (!e->valid) {
+        o << "null";
+      } else if (e->type == QE_TYPE_FLOAT64) {
+        uint64_t bits;
+        std::memcpy(&bits, &e->fval, 8);
+        o << std::hex << bits << std::dec;
+      } else if (e->type == QE_TYPE_UTF8) {
+        o << e->sval.size() << ":" << e->sval;
+      } else {
+        o << e->ival;
+      }
+      break;
+    case EK_BINARY:
+      if (e->to_f64) o << "f64(" << expr_identity(e->l) << ")";
+      else o << "(" << expr_identity(e->l) << " " << e->op << " " << expr_identity(e->r) << ")";
+      break;
+    case EK_HASH_UTF8: o << "hash(" << expr_identity(e->l) << ")"; break;
+    case EK_KEY_HASH: o << "keyhash(" << expr_identity(e->l) << "," << expr_identity(e->r) << ")"; break;
+    case EK_ROWID: o << "rowid(" << e->ival << ")"; break;
+  }
+  return o.str();
+}
+
 bool expr_is_scalar(const ExprPtr &e) {
   switch (e->kind) {
     case EK_COLUMN: return false;

@@ -163,6 +163,7 @@ ExprPtr make_hash_utf8(ExprPtr column);
 ExprPtr make_key_hash(ExprPtr before, ExprPtr column);
 ExprPtr make_rowid(int64_t base);
 std::string expr_to_string(const ExprPtr &e);
+std::string expr_identity(const ExprPtr &e);  // equal exactly for equal trees (expr_to_string is the reference's ambiguous Display)
 bool expr_is_scalar(const ExprPtr &e);
 
 struct ColInfo {

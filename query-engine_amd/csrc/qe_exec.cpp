@@ -545,11 +545,11 @@ struct AggSpec {
 static int add_acc(AggSpec &spec, uint8_t op, int in_type, bool track_nn, const ExprPtr &input) {
   // aggregates over the same input share one accumulator (AVG(x) next to SUM(x) / COUNT(x))
   // the row-number input differs between batches only in its base: one accumulator all the same
-  std::string key = input ? (input->kind == EK_ROWID ? std::string("rowid") : expr_to_string(input)) : std::string();
+  std::string key = input ? (input->kind == EK_ROWID ? std::string("rowid") : expr_identity(input)) : std::string();
   for (size_t i = 0; i < spec.accs.size(); ++i) {
     AccDesc &d = spec.accs[i];
     if (d.acc.op == op && d.acc.in_type == (uint8_t)in_type && (d.input != nullptr) == (input != nullptr) &&
-        (!input || (d.input->kind == EK_ROWID ? std::string("rowid") : expr_to_string(d.input)) == key)) {
+        (!input || (d.input->kind == EK_ROWID ? std::string("rowid") : expr_identity(d.input)) == key)) {
       if (track_nn) d.acc.track_nn = 1;
       return (int)i;
     }
@@ -810,7 +810,7 @@ static bool spill_enabled() {
 }
 
 // Decides on the mode for one launch and, when on, attaches the log buffers to `args`.
-static SpillPlan plan_spill(Context *ctx, const AggSpec &bspec, AggArgs &args, int64_t group_hint) {
+static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &bspec, AggArgs &args, int64_t group_hint) {
   SpillPlan sp;
   std::memset(args.spill_col, 0xff, sizeof(args.spill_col));
   std::memset(sp.acc_col, 0xff, sizeof(sp.acc_col));
@@ -819,8 +819,9 @@ static SpillPlan plan_spill(Context *ctx, const AggSpec &bspec, AggArgs &args, i
   std::vector<std::string> inputs;
   for (int i = 0; i < args.n_accs; ++i) {
     const AccDesc &d = bspec.accs[i];
-    if (!d.input || args.accs[i].track_nn || args.accs[i].op == ACC_COUNT) return sp;
-    std::string key = expr_to_string(d.input) + (d.input->to_f64 ? "#f64" : "");
+    // (a float64 MIN / MAX has no validity tracking of its own - a null is skipped like a NaN - but its input can be null all the same)
+    if (!d.input || args.accs[i].track_nn || args.accs[i].op == ACC_COUNT || expr_nullable(d.input, schema)) return sp;
+    std::string key = expr_identity(d.input);
     size_t col = 0;
     while (col < inputs.size() && inputs[col] != key) ++col;
     if (col == inputs.size()) {
@@ -1083,7 +1084,7 @@ struct AggState {
     args.n_rows = in.rows;
     args.lds_cap = aggregate_lds_slots(args.n_accs, ctx->dev, cap_hint);
     args.lds_limit = args.lds_cap - args.lds_cap / 4;
-    SpillPlan sp = plan_spill(ctx, bspec, args, cap_hint);
+    SpillPlan sp = plan_spill(ctx, schema, bspec, args, cap_hint);
     const char *kname = "qe_aggregate_kernel";
     ctx->prof_begin(kname, in.rows);
     QE_HIP(launch_aggregate(args, ctx->dev, ctx->stream, &kname));

@@ -334,6 +334,26 @@ def test_aggregate_types_and_keys(qe, ctx):
     assert out[1].validity is not None and not out[1].validity[0]  # max over only-NaN input is null
 
 
+def test_aggregate_inputs_that_print_alike(qe, ctx):
+    """The reference's Display prints column 2 and the literal 2 alike ("#2") and no parentheses: aggregates share an
+    accumulator only when their inputs are the same tree, not the same text."""
+    cols = agg_columns(20_000, 30, seed=17, key_dtype=np.int32)
+    v, f = C(2), C(5)
+    aggs = [("sum", v), ("sum", ("f64", 2.0)), ("avg", v), ("avg", ("f64", 2.0)), ("max", ("f64", 2.0)), ("max", v),
+            ("sum", ("mul", ("add", v, f), f)), ("sum", ("add", v, ("mul", f, f))), ("sum", C(3)), ("sum", ("i64", 3)), ("count", ("i64", 3))]
+    run_agg(qe, ctx, [cols], [C(0)], aggs, what="inputs that print alike")
+    run_agg(qe, ctx, [cols], [C(0)], aggs, hint=70_000, what="inputs that print alike, high-cardinality mode")
+
+
+def test_high_cardinality_mode_with_nullable_inputs(qe, ctx):
+    """A group-count hint that asks for the high-cardinality mode, whose row log carries values only: nullable inputs
+    (a float64 MIN / MAX tracks no validity of its own) keep the aggregate on the tables."""
+    parts = [agg_columns(30_000, 3000, seed=1, key_dtype=np.int32), agg_columns(7, 3000, seed=2, key_dtype=np.int32)]
+    x = ("add", ("sub", ("add", C(2), ("f64", 1.0)), ("sub", ("f64", 0.5), C(2))), C(2))
+    for groups in ([C(0)], [C(1), C(0)], [C(1), ("mod", C(0), ("i32", 7)), C(0)]):
+        run_agg(qe, ctx, parts, groups, [("max", x), ("min", x), ("max", C(2)), ("sum", C(5))], hint=200_000, what=f"nullable float64 min / max, {len(groups)} keys")
+
+
 def test_aggregate_batches_filter_growth_and_errors(qe, ctx):
     parts = [agg_columns(n, 500, seed=s, zipf=True) for n, s in ((40_000, 1), (1, 2), (25_000, 3), (4096, 4))]
     run_agg(qe, ctx, parts, [C(0)], ALL_AGGS_F64, what="four batches, skewed keys")

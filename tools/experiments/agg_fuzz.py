@@ -1,0 +1,71 @@
+"""Seeded random aggregations against the oracle: key tuples (plain, computed, boolean, hashed), aggregate lists
+of random kinds and inputs (short ones and ones that must be split), predicates, batch shapes, group-count hints
+(table growth, the high-cardinality mode), key ranges on both sides of the dense bins."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: F401  (before the engine: one HIP runtime)
+import importlib
+
+qe = importlib.import_module("query-engine_amd")
+from oracle import oracle as orc
+import test_gpu_trees as T
+from test_gpu_parity import C, agg_columns, run_agg
+
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+ctx = qe.Context(0)
+ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | (qe.FLAG_JIT_SYNC if os.environ.get("QE_FUZZ_JIT") == "1" else 0))
+r = np.random.default_rng(seed0)
+bad = 0
+for it in range(rounds):
+    n_keys = int(r.choice([1, 3, 10, 16, 40, 3000, 50_000]))
+    nulls = bool(r.integers(0, 2))
+    key_dtype = np.int32 if r.random() < 0.4 else np.int64
+    sizes = [int(r.choice([1, 7, 255, 4097, 30_000, 120_000])) for _ in range(int(r.integers(1, 4)))]
+    if n_keys == 50_000:
+        sizes = [150_000]
+    cols = [agg_columns(n, n_keys, seed=seed0 * 1000 + it * 10 + j, key_dtype=key_dtype, nulls=nulls, zipf=bool(r.integers(0, 2))) for j, n in enumerate(sizes)]
+    key_pool = [C(0), C(1), ("mod", C(4), ("i32", 5)), ("gt", C(5), ("f64", 0.5)), ("mod", C(0), ("i32" if key_dtype == np.int32 else "i64", 7))]
+    nk = int(r.choice([0, 1, 1, 1, 2, 3, 5]))
+    groups = [key_pool[i] for i in r.choice(len(key_pool), size=min(nk, len(key_pool)), replace=False)] if nk else []
+    inputs = [C(2), C(3), C(4), C(5), ("mul", C(2), C(5)), ("add", C(5), ("f64", 1.5)), ("sub", C(3), ("i64", 7)), ("mul", C(4), ("i32", 3)),
+              T.random_f64_over_agg_columns(r, int(r.integers(1, 5)))]
+    na = int(r.choice([1, 2, 3, 6, 12, 22]))
+    aggs = []
+    for _ in range(na):
+        kind = ["sum", "max", "min", "avg", "count"][r.integers(0, 5)]
+        aggs.append((kind, None) if kind == "count" and r.random() < 0.4 else (kind, inputs[r.integers(0, len(inputs))]))
+    pred = None if r.random() < 0.5 else ("gt", C(5), ("f64", float(r.choice([0.0, 0.25, 0.9, 1.0]))))
+    hint = int(r.choice([0, 0, 8, 64, 70_000, 200_000]))
+    what = f"it={it} keys={n_keys} nulls={nulls} {key_dtype.__name__} sizes={sizes} groups={groups} aggs={aggs} pred={pred} hint={hint}"
+    try:
+        run_agg(qe, ctx, cols, groups, aggs, hint=hint, pred=pred, what=what)
+    except orc.OracleError as e:
+        # the oracle refuses it: the product must refuse it the same way
+        try:
+            from test_gpu_parity import mk
+            from util import gpu_batch
+            src = qe.ScanExec(ctx, [gpu_batch(qe, ctx, c) for c in cols])
+            src = src if pred is None else qe.SelectionExec([src], mk(qe, pred))
+            list(qe.AggregateExec([src], [mk(qe, g) for g in groups], [mk(qe, a) for a in aggs], group_capacity_hint=hint).execute())
+            bad += 1
+            print("FAIL (oracle raised", e.name, "product did not)", what, flush=True)
+        except qe.QeError as e2:
+            if e2.name != e.name:
+                bad += 1
+                print("FAIL (error names differ)", e.name, e2.name, what, flush=True)
+    except BaseException as e:  # noqa: BLE001
+        bad += 1
+        print("FAIL", repr(e)[:400], what, flush=True)
+    if bad > 5:
+        sys.exit(1)
+    if it % 10 == 9:
+        print("iteration", it + 1, "failures", bad, flush=True)
+print("done; failures:", bad, flush=True)
+sys.exit(1 if bad else 0)
