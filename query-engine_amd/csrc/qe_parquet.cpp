@@ -862,6 +862,10 @@ std::shared_ptr<ParquetFile> parquet_open(const std::string &path) {
     }
     f->row_groups.push_back(rg);
   }
+  int64_t group_total = 0;
+  for (auto &rg : f->row_groups) group_total += rg.num_rows;
+  if (group_total != f->num_rows)
+    bad_file("the row groups hold " + std::to_string(group_total) + " rows, the footer says " + std::to_string(f->num_rows));
   return f;
 }
 
