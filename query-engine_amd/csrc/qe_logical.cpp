@@ -216,29 +216,43 @@ static std::string format_logical_plan(const LogicalPlanPtr &p, int indent) {
   return s;
 }
 
-// Projection push-down (optimizer.rs:15-58): every column an operator above the scan names is
-// collected on the way down; the scan then reads only those.
-static LogicalPlanPtr push_down(const LogicalPlanPtr &p, std::set<std::string> &cols) {
+// Projection push-down (optimizer.rs:15-58): the columns the operators above the scan need are collected on
+// the way down; the scan then reads only those.  `cols` is what the operators above `p` need of p's output.
+// Where the reference only ever adds names on the way down, here
+//  * a Projection or Aggregate starts the set afresh (what lies above them names their outputs, not the scan's
+//    columns), which prunes more;
+//  * a plan whose root is a Selection or the Scan itself needs every column of that root - they are the query's
+//    output (the reference would hand such a scan the predicate's columns only, or none at all).
+static LogicalPlanPtr push_down(const LogicalPlanPtr &p, std::set<std::string> &cols, bool root) {
   switch (p->kind) {
     case LP_SCAN: {
-      if (p->has_projection) cols.insert(p->projection.begin(), p->projection.end());
+      if (root) return p;
+      if (p->has_projection) {
+        // an earlier pass already narrowed the scan: nothing outside its projection exists any more
+        std::set<std::string> both;
+        for (auto &n : p->projection)
+          if (cols.count(n)) both.insert(n);
+        cols = both;
+      }
       return make_scan(p->path, p->source_schema, p->batches, p->parquet, true, std::vector<std::string>(cols.begin(), cols.end()));
     }
     case LP_AGGREGATE: {
+      cols.clear();
       for (auto &e : p->group_exprs) extract_columns(e, cols);
       for (auto &e : p->aggregate_exprs) extract_columns(e, cols);
-      return make_aggregate(push_down(p->child, cols), p->group_exprs, p->aggregate_exprs);
+      return make_aggregate(push_down(p->child, cols, false), p->group_exprs, p->aggregate_exprs);
     }
     case LP_PROJECTION: {
+      cols.clear();
       for (auto &e : p->exprs) extract_columns(e, cols);
-      return make_projection(push_down(p->child, cols), p->exprs);
+      return make_projection(push_down(p->child, cols, false), p->exprs);
     }
     default: {
-      // unlike the reference's Selection, this one passes its input's columns through: everything
-      // the input produces stays needed
-      for (auto &f : p->child->schema) cols.insert(f.name);
+      // a Selection passes its input's columns through: what is needed above it, and what its predicate reads
+      if (root)
+        for (auto &f : p->schema) cols.insert(f.name);
       extract_columns(p->exprs[0], cols);
-      return make_selection(push_down(p->child, cols), p->exprs[0]);
+      return make_selection(push_down(p->child, cols, false), p->exprs[0]);
     }
   }
 }
@@ -508,7 +522,7 @@ qe_status qe_dataframe_optimize(qe_dataframe *df, qe_dataframe **out) {
     if (!df || !out) fail(QE_ERR_INVALID_ARGUMENT, "bad arguments");
     std::unique_ptr<qe_dataframe> own(df);
     std::set<std::string> cols;
-    *out = new qe_dataframe{own->ctx, push_down(own->plan, cols)};
+    *out = new qe_dataframe{own->ctx, push_down(own->plan, cols, true)};
   });
 }
 

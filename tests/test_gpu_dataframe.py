@@ -94,6 +94,26 @@ def test_plan_display_optimizer_and_errors(qe, userdata):
     assert e.value.name == "PhysicalExpressionNotSuported"
 
 
+def test_optimizer_keeps_what_the_root_outputs(qe, userdata):
+    """Projection push-down prunes to what the operators above the scan need; a root that is the scan itself or a
+    Selection outputs every column (the reference's pass, optimizer.rs:20-57, would leave such a scan the
+    predicate's columns only, or none)."""
+    df, _, _ = userdata
+    P = qe.prelude
+    female = lambda: P.col("gender").eq(P.lit_string("Female"))
+    assert len(df.optimize().execute()[0].columns()) == 13
+    out = df.filter(female()).optimize().execute()[0]
+    assert len(out.columns()) == 13 and out.num_rows == 482
+    q = df.filter(female()).project([P.col("email")]).optimize()
+    assert "projection=email, gender" in q.logical_plan()  # not every column the Selection passes through
+    out = q.execute()[0]
+    assert len(out.columns()) == 1 and out.num_rows == 482 and out.columns()[0].values[0] == b"ajordan0@com.com"
+    # names above a Projection are its outputs' names, not the scan's: `id` is not read for them
+    q = df.project([P.col("salary") * P.lit_float(2.0), P.col("country")]).aggregate([P.col("country")], [P.max(P.col("mul"))]).optimize()
+    assert "projection=country, salary" in q.logical_plan()
+    assert q.optimize().logical_plan() == q.logical_plan()  # a second pass changes nothing
+
+
 def test_dataframe_query_matches_physical_oracle(qe, ctx):
     """filter -> project -> group by through the DataFrame API equals the oracle's physical plan with
     the indices the planner must have resolved."""

@@ -1,0 +1,170 @@
+"""Seeded random queries through the DataFrame API (names resolved by the planner, with and without the
+optimizer's projection push-down) against the oracle's physical plan built with the indices the planner must
+have found."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: F401
+import importlib
+
+qe = importlib.import_module("query-engine_amd")
+from oracle import oracle as orc
+from test_gpu_parity import _rows_by_key, mk
+from util import assert_batch_equal, gpu_batch
+
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+ctx = qe.Context(0)
+ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP)
+P = qe.prelude
+r = np.random.default_rng(seed0)
+bad = 0
+NAMES = ["k", "g", "s", "i", "l", "x", "y", "b"]
+TYPES = ["i64", "i32", "str", "i32", "i64", "f64", "f64", "bool"]
+WORDS = ["", "red", "green", "blue", "a longer word"]
+
+
+def table(n, seed):
+    q = np.random.default_rng(seed)
+    return [orc.Array(orc.INT64, q.integers(0, 30, n), q.random(n) > 0.03), orc.Array(orc.INT32, q.integers(-2, 3, n).astype(np.int32)),
+            orc.Array.from_python([None if v == 0 else WORDS[v % len(WORDS)] for v in q.integers(0, 20, n)]),
+            orc.Array(orc.INT32, q.integers(-1000, 1000, n).astype(np.int32), q.random(n) > 0.1), orc.Array(orc.INT64, q.integers(-10 ** 9, 10 ** 9, n)),
+            orc.Array(orc.FLOAT64, q.uniform(-5, 5, n), q.random(n) > 0.1), orc.Array(orc.FLOAT64, q.uniform(0, 1, n)), orc.Array(orc.BOOLEAN, q.random(n) < 0.5)]
+
+
+LIT = {"i64": lambda: (P.lit_int64, "i64", int(r.integers(-5, 30))), "i32": lambda: (P.lit_int, "i32", int(r.integers(-3, 4))),
+       "f64": lambda: (P.lit_float, "f64", float(r.integers(-8, 9)) / 4)}
+
+
+def pick(cols, types):
+    """Index (into the current columns) of a column of one of `types`, or None."""
+    c = [i for i, (_, t) in enumerate(cols) if t in types]
+    return int(r.choice(c)) if c else None
+
+
+def numeric(cols, t, depth):
+    """(logical expression, oracle spec) of type t over the current columns."""
+    i = pick(cols, [t])
+    if depth == 0 or r.random() < 0.3 or i is None:
+        if i is not None and r.random() < 0.8:
+            return P.col(cols[i][0]), ("col", i)
+        f, tag, v = LIT[t]()
+        return f(v), (tag, v)
+    op = ["add", "sub", "mul"][r.integers(0, 3)]
+    (la, sa), (lb, sb) = numeric(cols, t, depth - 1), numeric(cols, t, depth - 1)
+    return {"add": la + lb, "sub": la - lb, "mul": la * lb}[op], (op, sa, sb)
+
+
+def has_col(s):
+    return s[0] == "col" or (len(s) == 3 and isinstance(s[1], tuple) and (has_col(s[1]) or has_col(s[2])))
+
+
+def predicate(cols, depth):
+    p = r.random()
+    if depth > 0 and p < 0.35:
+        (la, sa), (lb, sb) = predicate(cols, depth - 1), predicate(cols, depth - 1)
+        return (la.and_(lb), ("and", sa, sb)) if r.random() < 0.5 else (la.or_(lb), ("or", sa, sb))
+    i = pick(cols, ["str"])
+    if i is not None and p < 0.5:
+        w = WORDS[r.integers(0, len(WORDS))]
+        return (P.col(cols[i][0]).eq(P.lit_string(w)), ("eq", ("col", i), ("str", w))) if r.random() < 0.5 else \
+               (P.col(cols[i][0]).neq(P.lit_string(w)), ("neq", ("col", i), ("str", w)))
+    i = pick(cols, ["bool"])
+    if i is not None and p < 0.6:
+        return P.col(cols[i][0]), ("col", i)
+    ts = [t for t in ("i64", "i32", "f64") if pick(cols, [t]) is not None]
+    if not ts:
+        return P.lit_bool(True), ("bool", True)
+    t = ts[r.integers(0, len(ts))]
+    (la, sa), (lb, sb) = numeric(cols, t, 1), numeric(cols, t, 1)
+    if not has_col(sa) and not has_col(sb):
+        i = pick(cols, [t])
+        la, sa = P.col(cols[i][0]), ("col", i)
+    op = ["gt", "lt", "gteq", "lteq", "eq", "neq"][r.integers(0, 6)]
+    return getattr(la, op)(lb), (op, sa, sb)
+
+
+for it in range(rounds):
+    sizes = [int(r.choice([1, 300, 4097, 20_000])) for _ in range(int(r.integers(1, 3)))]
+    parts = [table(n, seed0 * 1000 + it * 10 + j) for j, n in enumerate(sizes)]
+    df = qe.DataFrame.from_batches(ctx, NAMES, [gpu_batch(qe, ctx, p) for p in parts])
+    cols = list(zip(NAMES, TYPES))           # the current output columns (name, type)
+    plan = lambda m, scan: scan              # the oracle / product physical plan built alongside
+    text = []
+    try:
+        for _ in range(int(r.integers(0, 4))):
+            if r.random() < 0.5:
+                lp, sp = predicate(cols, int(r.integers(0, 3)))
+                df = df.filter(lp)
+                plan = (lambda prev, sp: lambda m, scan: m.SelectionExec([prev(m, scan)], mk(m, sp)))(plan, sp)
+                text.append(f"filter {sp}")
+            else:
+                keep = [int(i) for i in r.permutation(len(cols))[: int(r.integers(1, len(cols) + 1))]]
+                df = df.project([P.col(cols[i][0]) for i in keep])
+                plan = (lambda prev, keep: lambda m, scan: m.ProjectionExec([prev(m, scan)], [mk(m, ("col", i)) for i in keep]))(plan, keep)
+                cols = [cols[i] for i in keep]
+                text.append(f"project {[c[0] for c in cols]}")
+        aggregate = r.random() < 0.5
+        if aggregate:
+            keyable = [i for i, (_, t) in enumerate(cols) if t in ("i64", "i32", "str", "bool")]
+            nk = min(len(keyable), int(r.choice([0, 1, 1, 2, 3])))
+            keys = [int(i) for i in r.permutation(keyable)[:nk]] if nk else []
+            aggs_l, aggs_s = [], []
+            for _ in range(int(r.integers(1, 5))):
+                ts = [t for t in ("i64", "i32", "f64") if pick(cols, [t]) is not None]
+                if not ts:
+                    break
+                t = ts[r.integers(0, len(ts))]
+                kind = ["max", "min", "count", "sum"][r.integers(0, 4)]
+                if kind == "sum" and t == "f64":
+                    kind = "max"  # exact comparison below
+                le, se = numeric(cols, t, int(r.integers(0, 3)))
+                if not has_col(se):
+                    i = pick(cols, [t])
+                    le, se = P.col(cols[i][0]), ("col", i)
+                aggs_l.append(getattr(P, kind)(le))
+                aggs_s.append((kind, se))
+            if not aggs_l:
+                aggregate = False
+        if aggregate:
+            df = df.aggregate([P.col(cols[i][0]) for i in keys], aggs_l)
+            final = (lambda prev: lambda m, scan: m.AggregateExec([prev(m, scan)], [mk(m, ("col", i)) for i in keys], [mk(m, a) for a in aggs_s]))(plan)
+            text.append(f"aggregate keys={[cols[i][0] for i in keys]} aggs={aggs_s}")
+        else:
+            final = plan
+        if r.random() < 0.5:
+            df = df.optimize()
+            text.append("optimize")
+        what = f"it={it} sizes={sizes} " + " | ".join(text)
+        try:
+            want = list(final(orc, orc.ScanExec([orc.Chunk(p) for p in parts])).execute())
+        except orc.OracleError as e:
+            try:
+                df.execute()
+                raise AssertionError(f"oracle raised {e.name}, the product did not")
+            except qe.QeError as e2:
+                assert e2.name == e.name, (e.name, e2.name)
+            continue
+        got = df.execute()
+        if aggregate:
+            g = _rows_by_key(got[0].columns(), len(keys), False)
+            w = _rows_by_key(want[0].arrays, len(keys), True)
+            assert g == w, f"{len(g)} vs {len(w)}; {next(((k, g.get(k), w[k]) for k in w if g.get(k) != w[k]), None)}"
+        else:
+            assert len(got) == len(want), (len(got), len(want))
+            for a, b in zip(got, want):
+                assert_batch_equal(a, b, what="df")
+    except BaseException as e:  # noqa: BLE001
+        bad += 1
+        print("FAIL", repr(e)[:500], f"it={it} sizes={sizes} " + " | ".join(text), flush=True)
+        if bad > 5:
+            sys.exit(1)
+    if it % 20 == 19:
+        print("iteration", it + 1, "failures", bad, flush=True)
+print("done; failures:", bad, flush=True)
+sys.exit(1 if bad else 0)
