@@ -92,7 +92,28 @@ def predicate(cols, depth):
 for it in range(rounds):
     sizes = [int(r.choice([1, 300, 4097, 20_000])) for _ in range(int(r.integers(1, 3)))]
     parts = [table(n, seed0 * 1000 + it * 10 + j) for j, n in enumerate(sizes)]
-    df = qe.DataFrame.from_batches(ctx, NAMES, [gpu_batch(qe, ctx, p) for p in parts])
+    if r.random() < 0.35:
+        # the same table as a Parquet file (one row group per part), scanned by the engine's own reader
+        import tempfile
+        import pyarrow as pa
+        import pyarrow.parquet as pq
+
+        def to_arrow(a):
+            if a.type == orc.UTF8:
+                return pa.array([None if v is None else v for v in a.to_pylist()], type=pa.string())
+            return pa.array(a.values, mask=None if a.validity is None else ~a.validity)
+        path = os.path.join(tempfile.gettempdir(), f"dffuzz_{os.getpid()}.parquet")
+        writer = None
+        for p in parts:
+            t = pa.table({n: to_arrow(a) for n, a in zip(NAMES, p)})
+            writer = writer or pq.ParquetWriter(path, t.schema, compression=str(r.choice(["none", "snappy"])))
+            writer.write_table(t)
+        writer.close()
+        df = qe.DataFrame.parquet(ctx, path)
+        from_file = True
+    else:
+        df = qe.DataFrame.from_batches(ctx, NAMES, [gpu_batch(qe, ctx, p) for p in parts])
+        from_file = False
     cols = list(zip(NAMES, TYPES))           # the current output columns (name, type)
     plan = lambda m, scan: scan              # the oracle / product physical plan built alongside
     text = []
@@ -140,7 +161,7 @@ for it in range(rounds):
         if r.random() < 0.5:
             df = df.optimize()
             text.append("optimize")
-        what = f"it={it} sizes={sizes} " + " | ".join(text)
+        what = f"it={it} sizes={sizes} file={from_file} " + " | ".join(text)
         try:
             want = list(final(orc, orc.ScanExec([orc.Chunk(p) for p in parts])).execute())
         except orc.OracleError as e:
@@ -161,7 +182,7 @@ for it in range(rounds):
                 assert_batch_equal(a, b, what="df")
     except BaseException as e:  # noqa: BLE001
         bad += 1
-        print("FAIL", repr(e)[:500], f"it={it} sizes={sizes} " + " | ".join(text), flush=True)
+        print("FAIL", repr(e)[:500], f"it={it} sizes={sizes} file={from_file} " + " | ".join(text), flush=True)
         if bad > 5:
             sys.exit(1)
     if it % 20 == 19:
