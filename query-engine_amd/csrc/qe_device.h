@@ -783,10 +783,33 @@ __device__ __forceinline__ int64_t global_find_or_claim(const AggTable &T, uint6
       }
       if (old == key) return (int64_t)s;
     }
+    // A long probe sequence means a crowded table.  Once 7/8 of the slots are taken the table counts as full:
+    // the host starts over with a larger one, and walking a full table slot by slot for every further key
+    // (minutes, for a million keys against 65 536 slots) serves nobody; a table already given up is left at once.
+    if ((p & 31) == 8) {
+      if (__hip_atomic_load(&T.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return -1;
+      if (__hip_atomic_load(&T.ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= T.cap - T.cap / 8) break;
+    }
     s = (s + 1) & mask;
   }
   atomicExch(&T.ctrl[1], 1ull);
   return -1;
+}
+
+// A group table that has been given up (full: the host starts over with a larger one) makes the rest of the
+// launch pointless; the waves look every 64th wave-step and leave.  A look is a load whose result is only
+// read at the start of the next step - by then the step's own column loads have been waited for, and this
+// one with them - so that the wave never waits for it.
+struct GiveUpWatch {
+  bool on = true;  // off in high-cardinality mode: its first phase logs rows and leaves the table alone
+  uint32_t steps = 0;
+  unsigned long long seen = 0;
+};
+__device__ __forceinline__ bool table_given_up(const AggTable &T, GiveUpWatch &w) {
+  if (!w.on) return false;
+  const bool lost = __builtin_amdgcn_readfirstlane((int)(w.seen != 0)) != 0;
+  if ((w.steps++ & 63u) == 63u) w.seen = __hip_atomic_load(&T.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return lost;
 }
 
 // Cheap 32-bit hash for the LDS table (the global table uses the full mix64).

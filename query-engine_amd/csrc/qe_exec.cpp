@@ -940,8 +940,15 @@ struct AggState {
   static int acc_weight(const AggExpr &a) { return a.kind == QE_AGG_AVG ? 2 : 1; }  // accumulators an aggregate may take
   static constexpr int PART_ACC_BUDGET = VM_MAX_ACCS - 2;                           // the row number, and one to spare
 
+  // What the kernels' choices (LDS table size, high-cardinality mode) go by: the caller's group-count hint, or -
+  // once a table has overflowed and the aggregation starts over with a larger one - what that taught.
+  int64_t last_start_hint = 0, learned_hint = 0;
+  int64_t effective_hint() const { return std::max(cap_hint, learned_hint); }
+
   // Fresh table for about `hint` groups.
   void start(int64_t hint) {
+    if (last_start_hint > 0 && hint > last_start_hint) learned_hint = std::max(learned_hint, hint);
+    last_start_hint = hint;
     deferred_finishes = 0;
     deferred_block.reset();
     cap = 1024;
@@ -957,7 +964,7 @@ struct AggState {
         p->strict = strict;
         p->groups = groups;
         p->mode = mode;
-        p->cap_hint = cap_hint;
+        p->cap_hint = effective_hint();
         p->emit_row_number = true;
         for (int w = 0; i < aggs.size() && (w == 0 || w + acc_weight(aggs[i]) <= PART_ACC_BUDGET); ++i) {
           w += acc_weight(aggs[i]);
@@ -1082,14 +1089,14 @@ struct AggState {
     lower_aggregate(comp, schema, pred_n, bspec, spec, args);
     args.table = table;
     args.n_rows = in.rows;
-    args.lds_cap = aggregate_lds_slots(args.n_accs, ctx->dev, cap_hint);
+    args.lds_cap = aggregate_lds_slots(args.n_accs, ctx->dev, effective_hint());
     args.lds_limit = args.lds_cap - args.lds_cap / 4;
-    SpillPlan sp = plan_spill(ctx, schema, bspec, args, cap_hint);
+    SpillPlan sp = plan_spill(ctx, schema, bspec, args, effective_hint());
     const char *kname = "qe_aggregate_kernel";
     ctx->prof_begin(kname, in.rows);
     QE_HIP(launch_aggregate(args, ctx->dev, ctx->stream, &kname));
     ctx->prof_end(kname);
-    if (sp.on) aggregate_spilled(ctx, sp, args, cap_hint);
+    if (sp.on) aggregate_spilled(ctx, sp, args, effective_hint());
     if (!comp.keepalive.empty()) ctx->sync();
   }
 
@@ -1296,7 +1303,9 @@ struct AggIter : Iter {
         done = true;
         return;
       }
-      hint = (int64_t)st.cap * 4;  // grow and run the aggregation again
+      // grow (a full table says little about how many groups there are: a big step, up to the largest table) and run the aggregation again
+      if (st.cap >= (1ull << 30)) break;
+      hint = std::min<int64_t>((int64_t)st.cap * 16, (int64_t)1 << 29);
     }
     fail(QE_ERR_AGG_CAPACITY, "group table still full after growing");
   }
@@ -2140,7 +2149,8 @@ qe_status qe_agg_finalize(qe_agg_state *state, qe_batch **out) {
         return;
       }
       // the table overflowed: a larger one, and everything seen so far folded in again
-      state->hint = (int64_t)state->st.cap * 4;
+      if (state->st.cap >= (1ull << 30)) break;
+      state->hint = std::min<int64_t>((int64_t)state->st.cap * 16, (int64_t)1 << 29);
       state->st.start(state->hint);
       for (auto &b : state->history) state->st.update(b, {}, nullptr);
     }

@@ -161,8 +161,11 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, FULL ? 2 : 3) void qe_aggregate_k
   SpillState sp = spill_begin(A.spill, wave);
 
   const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
+  GiveUpWatch steps_done;
+  steps_done.on = A.spill.keys == nullptr;
   for (int64_t ws = (int64_t)blockIdx.x * VM_BLOCK_WAVES + wave; ws < nsteps;
        ws += (int64_t)gridDim.x * VM_BLOCK_WAVES) {
+    if (table_given_up(A.table, steps_done)) break;
     RowCtx c;
     c.row0 = ws * VM_WAVE_ROWS;
     c.n = n;

@@ -591,7 +591,7 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_aggregate_static(const
   hot_reset<Spec, 1>(C, true);
   SpillState sp = spill_begin(A.spill, wave);
 
-  const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
+  int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
   auto step = [&](int64_t row0, uint32_t active) __attribute__((always_inline)) {
     RowCtx c;
     c.row0 = row0;
@@ -619,16 +619,21 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_aggregate_static(const
   // (12 % less time for the 12-byte row); the wave's step counter then lives in scalar registers so that the
   // choice is a scalar branch.  Kernels with wider rows are bound by HBM and lose more to the registers the
   // second copy costs (occupancy) than they gain: one copy.
+  GiveUpWatch steps_done;
+  steps_done.on = A.spill.keys == nullptr;
   if constexpr (spec_row_bytes<Spec>() < 16) {
     const int64_t ws0 = (int64_t)blockIdx.x * VM_BLOCK_WAVES + __builtin_amdgcn_readfirstlane(wave);
     for (int64_t ws = ws0; ws < nsteps; ws += (int64_t)gridDim.x * VM_BLOCK_WAVES) {
+      if (table_given_up(A.table, steps_done)) nsteps = 0;  // (a shrinking bound, not a second exit: the loop keeps its shape)
       const int64_t row0 = ws * VM_WAVE_ROWS;
       if (row0 + VM_WAVE_ROWS <= n) step(row0, 0xFu);
       else step(row0, in_range_bits(row0, lane, n));
     }
   } else {
-    for (int64_t ws = (int64_t)blockIdx.x * VM_BLOCK_WAVES + wave; ws < nsteps; ws += (int64_t)gridDim.x * VM_BLOCK_WAVES)
+    for (int64_t ws = (int64_t)blockIdx.x * VM_BLOCK_WAVES + wave; ws < nsteps; ws += (int64_t)gridDim.x * VM_BLOCK_WAVES) {
+      if (table_given_up(A.table, steps_done)) nsteps = 0;
       step(ws * VM_WAVE_ROWS, in_range_bits(ws * VM_WAVE_ROWS, lane, n));
+    }
   }
   spill_end(A.spill, sp, wave, lane);
   __syncthreads();  // every wave's bin updates are in

@@ -156,3 +156,28 @@ def test_high_cardinality_mode(qe, ctx, n, n_keys, zipf):
         ctx.profile(False)
     if n_keys >= 100_000:
         assert "qe_aggregate_partitioned_kernel" in names, names
+
+
+def test_many_groups_without_a_hint(qe, ctx):
+    """A million groups and no group-count hint from the caller: the default table fills up, is given up at once
+    (not walked slot by slot for every further key, which took minutes), and the second attempt - sized, and
+    switched to the high-cardinality mode, by what the first taught - succeeds.  Counts against numpy."""
+    import time
+    n, groups = 8_000_000, 1_000_000
+    r = np.random.default_rng(31)
+    k = r.integers(0, groups, n)
+    v = r.uniform(0, 1, n)
+    batch = qe.Batch.from_numpy(ctx, [qe.Column(qe.TYPE_INT64, k), qe.Column(qe.TYPE_FLOAT64, v)]).to_device()
+    C = qe.ColumnExpression
+    t0 = time.perf_counter()
+    out = list(qe.AggregateExec([qe.ScanExec(ctx, [batch])], [C(0)], [qe.CountExpression(None), qe.MaxExpression(C(1))]).execute())[0]
+    cols = out.columns()
+    seconds = time.perf_counter() - t0
+    want = np.bincount(k, minlength=groups)
+    order = np.argsort(np.asarray(cols[0].values))
+    assert np.array_equal(np.asarray(cols[0].values)[order], np.nonzero(want)[0])
+    assert np.array_equal(np.asarray(cols[1].values)[order], want[want > 0])
+    mx = np.zeros(groups)
+    np.maximum.at(mx, k, v)
+    assert np.array_equal(np.asarray(cols[2].values)[order], mx[want > 0])
+    assert seconds < 20, seconds  # milliseconds of device time; the bound only has to catch the slot-by-slot walk
