@@ -749,7 +749,7 @@ __device__ __forceinline__ uint64_t acc_identity(uint32_t op) { return op == ACC
 
 constexpr int32_t SLOT_NONE = INT32_MIN;
 constexpr int32_t SLOT_LDS_MISS = -1;  // transient: no room in the LDS table, the row needs another home
-constexpr int LDS_MAX_PROBE = 8;
+constexpr int LDS_MAX_PROBE = 64;
 
 struct LdsTable {
   unsigned long long *keys;  // [cap + 1]

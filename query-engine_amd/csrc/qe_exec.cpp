@@ -791,7 +791,13 @@ static void lower_aggregate(Compiler &comp, const Schema &schema, const ExprPtr 
 // per row and accumulator is what the kernel then spends its time on.  When the caller's group-count
 // hint says so, those rows are logged instead (AggSpill), partitioned by key hash and aggregated
 // partition by partition in LDS: a few streaming passes over a fraction of the rows.
-constexpr int64_t SPILL_MIN_GROUP_HINT = 1 << 16;
+static int64_t spill_min_group_hint() {
+  static int64_t v = [] {
+    const char *e = getenv("QE_SPILL_MIN_GROUPS");
+    return e && atoll(e) > 0 ? (int64_t)atoll(e) : (int64_t)1 << 16;
+  }();
+  return v;
+}
 constexpr int SPILL_MAX_INPUTS = 8;
 
 struct SpillPlan {
@@ -814,7 +820,19 @@ static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &b
   SpillPlan sp;
   std::memset(args.spill_col, 0xff, sizeof(args.spill_col));
   std::memset(sp.acc_col, 0xff, sizeof(sp.acc_col));
-  if (!spill_enabled() || group_hint < SPILL_MIN_GROUP_HINT || args.n_rows >= (1ll << 31) || args.n_accs == 0) return sp;
+  // When: the caller promises many groups; or, for batches large enough to pay for the second phase's fixed
+  // costs, whenever the groups may outnumber a workgroup's LDS table - no hint at all, or one beyond the table.
+  // (What does not fit the LDS table would otherwise go to the global table row by row, where a few thousand
+  // keys mean heavily contended atomics: 64 M rows over 2 000 keys 44 ms, through the log 2.3 ms.)  A deferred
+  // aggregate promises its caller not to wait for the device, which the second phase does.
+  static const bool midrange = [] {
+    const char *e = getenv("QE_SPILL_MIDRANGE");
+    return e ? atoi(e) != 0 : true;
+  }();
+  const bool deferred = (ctx->flags & QE_FLAG_DEFERRED_GROUP_COUNT) != 0;
+  const bool wanted = group_hint >= spill_min_group_hint() ||
+                      (midrange && !deferred && args.n_rows >= (1 << 20) && (group_hint == 0 || group_hint >= 512));
+  if (!spill_enabled() || !wanted || args.n_rows >= (1ll << 31) || args.n_accs == 0) return sp;
   // the log carries values only: every accumulator must read a non-nullable input
   std::vector<std::string> inputs;
   for (int i = 0; i < args.n_accs; ++i) {

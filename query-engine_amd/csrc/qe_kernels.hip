@@ -374,13 +374,19 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
   none.cursor = 0;
   for (;;) {
     __syncthreads();
-    if (threadIdx.x == 0) s_ticket = atomicAdd(A.ticket, 1ull);
+    if (threadIdx.x == 0) {
+      s_ticket = atomicAdd(A.ticket, 1ull);
+      // a global table that has been given up (the host starts over with a larger one): no further partition
+      if (__hip_atomic_load(&A.table.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) s_ticket = (unsigned long long)A.n_parts;
+    }
     agg_lds_clear(L, A.accs, A.n_accs);  // ends with a barrier
     const int64_t p = (int64_t)s_ticket;
     if (p >= A.n_parts) break;
+    GiveUpWatch watch;
     const int64_t start = A.offsets[p * A.stride];
     const int64_t end = p + 1 < A.n_parts ? (int64_t)A.offsets[(p + 1) * A.stride] : A.total;
     for (int64_t r0 = start + (int64_t)wave * VM_WAVE_ROWS; r0 < end; r0 += (int64_t)n_waves * VM_WAVE_ROWS) {
+      if (table_given_up(A.table, watch)) break;
       AggRows G;
       uint32_t active = 0;
 #pragma unroll

@@ -155,6 +155,9 @@ def test_high_cardinality_mode(qe, ctx, n, n_keys, zipf):
     finally:
         ctx.profile(False)
     if n_keys >= 100_000:
+        assert "qe_spill_count_kernel" in names, names  # the mode was on
+    if n_keys >= 100_000 and not zipf:
+        # uniform keys overflow every workgroup's LDS table (the skewed ones, spread over the workgroups, need not)
         assert "qe_aggregate_partitioned_kernel" in names, names
 
 
@@ -181,3 +184,30 @@ def test_many_groups_without_a_hint(qe, ctx):
     np.maximum.at(mx, k, v)
     assert np.array_equal(np.asarray(cols[2].values)[order], mx[want > 0])
     assert seconds < 20, seconds  # milliseconds of device time; the bound only has to catch the slot-by-slot walk
+
+
+@pytest.mark.parametrize("groups,hint", [(300, 0), (2000, 0), (2000, 2000), (30_000, 0), (60_000, 0), (700, 700), (5000, 64)])
+def test_mid_cardinality_large_batches(qe, ctx, groups, hint):
+    """Batches of a million rows and more whose groups may outnumber a workgroup's LDS table (no hint, or a hint
+    beyond the table) go through the row log; a hint that undersells the groups stays on the tables.  SUM / MAX /
+    COUNT against numpy; small-integer keys, whose hash clusters in the LDS table were once a cliff."""
+    n = 3_000_000
+    r = np.random.default_rng(groups + hint)
+    k = r.integers(0, groups, n)
+    v = r.uniform(-1, 1, n)
+    batches = [qe.Batch.from_numpy(ctx, [qe.Column(qe.TYPE_INT64, k[s:e]), qe.Column(qe.TYPE_FLOAT64, v[s:e])]).to_device()
+               for s, e in ((0, 1_700_000), (1_700_000, n))]
+    E = qe.ColumnExpression
+    out = list(qe.AggregateExec([qe.ScanExec(ctx, batches)], [E(0)], [qe.SumExpression(E(1)), qe.MaxExpression(E(1)), qe.CountExpression(None)],
+                                group_capacity_hint=hint).execute())[0]
+    cols = out.columns()
+    order = np.argsort(np.asarray(cols[0].values))
+    cnt = np.bincount(k, minlength=groups)
+    assert np.array_equal(np.asarray(cols[0].values)[order], np.nonzero(cnt)[0])
+    assert np.array_equal(np.asarray(cols[3].values)[order], cnt[cnt > 0])
+    mx = np.full(groups, -np.inf)
+    np.maximum.at(mx, k, v)
+    assert np.array_equal(np.asarray(cols[2].values)[order], mx[cnt > 0])
+    sums = np.bincount(k, weights=v, minlength=groups)
+    mags = np.bincount(k, weights=np.abs(v), minlength=groups)
+    assert (np.abs(np.asarray(cols[1].values)[order] - sums[cnt > 0]) <= 1e-12 * mags[cnt > 0] + 1e-300).all()
