@@ -445,6 +445,14 @@ __device__ __forceinline__ void hot_fold(HotCache<Spec::n_accs> &C, const Slot &
   }
 }
 
+// Bytes of column values a row brings in through the column cache.
+template <class Spec>
+constexpr int spec_row_bytes() {
+  int b = 0;
+  for (uint32_t i = 0; i < Spec::cache_n; ++i) b += Spec::cache_kind[i] == CK_64 ? 8 : Spec::cache_kind[i] == CK_32 ? 4 : 1;
+  return b;
+}
+
 // Dense-key bins.  When the packed key of a row is a small number (a boolean, a category code, a
 // passenger count) nothing has to be looked up: the key addresses a bin directly.  Every lane has
 // bins of its own - rows[key][lane], acc[a][key][lane], shared by the workgroup's waves - so that
@@ -547,24 +555,19 @@ __device__ __forceinline__ void agg_tasks_static(const AggArgs &A, const LdsTabl
         for (int h = 0; h < HOT_KEYS; ++h) C.rows[h] += (uint32_t)__popc(hm[h]);
       }
       // rows of other keys: LDS / global table (no dominant-key search: the hot keys took those)
-      agg_lookup<false>(L, A.table, rest, lane, G, sp);
+      // (with the wave-wide reduction of a key that dominates what is left: skewed keys beyond the two hot ones
+      // would otherwise meet on one LDS address row by row - zipf s = 2 over 100 keys 2.1 ms per 64 M rows, with it
+      // 0.9 ms; the narrow-row kernels, whose body exists twice, have no registers to spare for it: 0.50 -> 0.72 ms)
+      agg_lookup<(spec_row_bytes<Spec>() >= 16)>(L, A.table, rest, lane, G, sp);
     } else {
       if (__ballot((hm[0] | hm[1]) != 0) != 0) hot_fold<Spec, (int)idx>(C, S[0], hm);
       if (dm != 0) dense_fold<Spec, (int)idx>(D, S[0], G.key, dm, lane);
       if (G.spill_mb != 0 && A.spill_col[idx] != 0xffu) spill_values(sp, A.spill_col[idx], S[0], G);
-      if (__ballot(G.rem != 0) != 0)
+      if (G.lead_slot != SLOT_NONE || __ballot(G.rem != 0) != 0)  // rows folded one by one, or a dominant key's through the wave
         agg_fold(L, A.table, idx, Spec::acc_op[idx], Spec::acc_type[idx], Spec::acc_track[idx] != 0, S[0], G, lane);
     }
     agg_tasks_static<Spec, T + 1>(A, L, D, dm, c, K, G, C, hm, sp, lane);
   }
-}
-
-// Bytes of column values a row brings in through the column cache.
-template <class Spec>
-constexpr int spec_row_bytes() {
-  int b = 0;
-  for (uint32_t i = 0; i < Spec::cache_n; ++i) b += Spec::cache_kind[i] == CK_64 ? 8 : Spec::cache_kind[i] == CK_32 ? 4 : 1;
-  return b;
 }
 
 template <class Spec>

@@ -105,3 +105,19 @@ def test_dense_key_bins(qe, jit_ctx):
     run_agg(qe, jit_ctx, [cols(40_000, 10, 0, 3)], [("gt", C(5), ("f64", 0.5)), C(1)], [("sum", C(2)), ("avg", C(5))], hint=64,
             what="boolean + int32 key packed together")
     assert any(k.startswith("qe_aggregate_jit<") for k in jit_kernels(jit_ctx))
+
+
+def test_skewed_keys_outside_the_bins(qe, jit_ctx):
+    """A few keys that dominate every wave-step, none of them small enough for the dense bins: two sit in the
+    hot-key registers, the next is reduced across the wave, the rest meet in the LDS table.  (Once the dominant
+    key's fold was skipped when no other row was left in a wave-step.)"""
+    n = 60_000
+    r = rng(19)
+    for shares in ([0.6, 0.25, 0.1, 0.05], [0.5, 0.5], [1.0], [0.34, 0.33, 0.33]):
+        keys = np.array([10_000 + 1000 * i for i in range(len(shares))], dtype=np.int64)
+        a = agg_columns(n, 1, seed=len(shares), nulls=False)
+        a[0] = orc.Array(orc.INT64, r.choice(keys, size=n, p=shares))
+        run_agg(qe, jit_ctx, [a, [orc.Array(x.type, x.values[:777]) for x in a]], [C(0)],
+                [("sum", C(2)), ("min", C(2)), ("max", C(3)), ("count", None), ("avg", C(5))], hint=64, what=f"skewed keys {shares}")
+        run_agg(qe, jit_ctx, [a], [("gt", C(5), ("f64", 0.5)), C(0)], [("sum", C(3)), ("count", None)], what=f"boolean next to skewed keys {shares}")
+    assert any(k.startswith("qe_aggregate_jit<") for k in jit_kernels(jit_ctx))
