@@ -67,19 +67,41 @@ def batch_as_block(torch, batch, n_cols):
     return torch.as_tensor(DevArray(base, words, "<i8"), device="cuda"), [o // 8 for o in offs], rows
 
 
+def load_launcher():
+    """query-engine_amd/launcher.py by path: importing the package would load the HIP library, and the ranks must be
+    started before this process has anything to do with a GPU."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("qe_launcher", os.path.join(ROOT, "query-engine_amd", "launcher.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launcher = load_launcher()
     # QE_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share
     # devices, the exchange goes through host memory); the measured configuration is nccl = RCCL.
     backend = os.environ.get("QE_BENCH_BACKEND", "nccl")
+    try:
+        world, rank, local_rank, launched = launcher.check_world(args.gpus)
+    except launcher.LaunchError as e:
+        print(f"bench.py: {e}", file=sys.stderr)
+        sys.exit(2)
+    import torch
+    n_devices = torch.cuda.device_count()  # does not initialise the device
+    if backend == "nccl" and n_devices < world:
+        print(f"bench.py: --gpus {world} needs {world} GPUs, this machine has {n_devices}: refusing to run fewer ranks than asked for "
+              "(QE_BENCH_BACKEND=gloo rehearses the multi-rank path with ranks sharing a device)", file=sys.stderr)
+        sys.exit(2)
+    if world > 1 and not launched:
+        # nobody started the ranks for us: N fresh children, before this process touches a GPU; rank 0 prints the line
+        os.environ["QE_BENCH_SPAWNED"] = "1"
+        sys.exit(launcher.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], world))
+    import torch.distributed as dist
+
     if backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()
+        local_rank = local_rank % max(1, n_devices)
     # QE_BENCH_FORCE_DIST=1 runs the multi-rank code path (PARTIAL aggregate, exchange, FINAL merge) with whatever
     # world size the launcher gave, 1 included: a one-GPU box can then exercise the real RCCL calls.
     multi = world > 1 or os.environ.get("QE_BENCH_FORCE_DIST") == "1"
@@ -186,6 +208,10 @@ def main():
         part = list(local_plan().execute())[0]
         if not multi:
             return part
+        return merge(part)
+
+    def merge(part):
+        """Exchange of this rank's partial table and the FINAL aggregate over what arrives."""
         cols = [column_as_tensor(torch, part.column_desc(i), qe) for i in range(3)]
         # the only collective of the plan: the exchange of the partial tables over xGMI
         if partitioned:
@@ -237,13 +263,37 @@ def main():
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
     ctx.profile(False)
+    # the merge alone (exchange + FINAL aggregate of one partial table), timed the same way: what N > 1 adds to a step
+    merge_ms = None
+    if multi and not two_streams:
+        part = list(local_plan().execute())[0]
+        merge(part)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            merge(part)
+        barrier()
+        merge_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        del part
     ctx.set_flags(default_flags)
     if ctx2 is not ctx:
         ctx2.set_flags(default_flags)
+    topology = {"world_size": world, "backend": "single process"}
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device=xdev)
+        t = torch.tensor([dt, merge_ms or 0.0], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(t[0].item())
+        merge_ms = float(t[1].item()) if merge_ms is not None else None
+        here = [None] * world
+        dist.all_gather_object(here, {"rank": rank, "device": local_rank, "pid": os.getpid(),
+                                      "name": torch.cuda.get_device_name(local_rank),
+                                      "pci_bus_id": getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None)})
+        topology = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                    "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
+                    "launched_by": "bench.py (child processes)" if os.environ.get("QE_BENCH_SPAWNED") else "external launcher" if launched else "none",
+                    "ranks": here}
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: ran {world} ranks but --gpus {args.gpus} was asked for")
     ms_per_step = dt / args.steps * 1e3
     value = total / (dt / args.steps)
 
@@ -283,7 +333,9 @@ def main():
                      "avg_launch_ms": avg_ms, "rows_per_launch": rows_per_launch},
         "pct_hbm_peak_per_gpu": 100.0 * (BYTES_PER_ROW["c5"] * n / (dt / args.steps)) / 1e9 / HBM_PEAK_GBS,
         "kernels": prof,
+        "merge_ms_per_step": merge_ms,
     }
+    out["config"]["topology"] = topology
 
     cols = result.columns()
     real = np.asarray(cols[2].values) > 0  # deferred mode pads the result to the table's slots
@@ -358,15 +410,50 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
     C = qe.ColumnExpression
     res = {}
 
-    def entry(name, rows, dt, prof, kernel, bpr, launches_per_step, extra=None):
+    def entry(name, rows, dt, prof, kernel, bpr, launches_per_step, extra=None, steps=5):
         kernel, kk = dominant_kernel(prof, kernel)
         avg = kk["ms"] / kk["launches"] if kk["launches"] else float("nan")
         gbs = bpr * rows / launches_per_step / (avg * 1e-3) / 1e9 if kk["launches"] else float("nan")
-        e = {"rows": rows, "rows_per_s": rows / dt, "ms_per_step": dt * 1e3, "kernel": kernel, "avg_launch_ms": avg,
-             "bytes_per_row": bpr, "kernel_GBps": gbs, "frac_hbm_peak": gbs / HBM_PEAK_GBS}
+        e2e = bpr * rows / dt / 1e9
+        # frac_hbm_peak_end_to_end: algorithmic bytes / whole step (every kernel, every host wait) - the figure to judge a
+        # multi-kernel configuration by; frac_hbm_peak_main_kernel: the same bytes over the dominant kernel's time alone
+        e = {"rows": rows, "rows_per_s": rows / dt, "ms_per_step": dt * 1e3, "bytes_per_row": bpr,
+             "end_to_end_GBps": e2e, "frac_hbm_peak_end_to_end": e2e / HBM_PEAK_GBS,
+             "kernel": kernel, "avg_launch_ms": avg, "kernel_GBps": gbs, "frac_hbm_peak_main_kernel": gbs / HBM_PEAK_GBS,
+             "kernels_ms_per_step": {kk: vv["ms"] / steps for kk, vv in prof.items()}}
         if extra:
             e.update(extra)
         res[name] = e
+
+    # The headline plan under the library's default flags (every aggregate waits for its group count and hands back
+    # exactly the groups, the reference's protocol, physical_plan/mod.rs:375-488): the deferred mode above is an option.
+    hb = [qe.Batch.from_torch(ctx, [t[s:min(n, s + args.batch_rows)] for t in (k, a, b, c)]) for s in range(0, n, args.batch_rows)]
+    keyed = lambda col: [qe.SumExpression(C(col)), qe.CountExpression(None)]
+
+    def headline_default():
+        sel = qe.SelectionExec([qe.ScanExec(ctx, hb)], qe.GtExpression(C(3), qe.LiteralFloatExpression(0.5)))
+        proj = qe.ProjectionExec([sel], [C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
+        return list(qe.AggregateExec([proj], [C(0)], keyed(1), group_capacity_hint=max(64, 2 * args.groups)).execute())[0]
+    dt, prof, out = timed(ctx, torch, headline_default, 5, 2)
+    entry("C5_headline_default_flags", n, dt, prof, "qe_aggregate", BYTES_PER_ROW["c5"], len(hb),
+          {"groups": out.num_rows, "host_sync": "per aggregate (group count read back, exact-size output)"})
+    del out
+
+    # A shape no kernel was built for ahead of time: key in column 2, predicate c < 0.3, value a*b - c.  The run-time
+    # compiler specialises it (QE_FLAG_JIT_SYNC: compile on first use, here during the warm-up steps).
+    rj = min(n, 500_000_000)
+    bj = [qe.Batch.from_torch(ctx, [t[s:min(rj, s + args.batch_rows)] for t in (a, b, k, c)]) for s in range(0, rj, args.batch_rows)]
+    ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_JIT_SYNC)
+
+    def jit_shape():
+        sel = qe.SelectionExec([qe.ScanExec(ctx, bj)], qe.LtExpression(C(3), qe.LiteralFloatExpression(0.3)))
+        proj = qe.ProjectionExec([sel], [C(2), qe.SubExpression(qe.MulExpression(C(0), C(1)), C(3))])
+        return list(qe.AggregateExec([proj], [C(0)], keyed(1), group_capacity_hint=64).execute())[0]
+    dt, prof, out = timed(ctx, torch, jit_shape, 5, 2)
+    entry("C5_shape_not_prebuilt_jit_500M", rj, dt, prof, "qe_aggregate", BYTES_PER_ROW["c5"], len(bj),
+          {"groups": out.num_rows, "plan": "Selection(c < 0.3) -> Projection(k, a*b - c) -> Aggregate(k; SUM, COUNT), columns (a, b, k, c)"})
+    ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP)
+    del out, bj, hb
 
     # C2: fused filter + project, 100 M rows, 50 % selectivity -> materialised, order-preserving output
     r2 = min(n, 100_000_000)
@@ -418,7 +505,7 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
                                      group_capacity_hint=1_100_000).execute())[0]
     dt, prof, out = timed(ctx, torch, c5m, 3, 1)
     entry("C5_plan_1M_groups_500M", r5, dt, prof, "qe_aggregate_static", BYTES_PER_ROW["c5"], len(b5),
-          {"groups": out.num_rows, "kernels_ms_per_step": {kk: vv["ms"] / 3 for kk, vv in prof.items()}})
+          {"groups": out.num_rows}, steps=3)
     del uk, b5, out
 
     # C4: 1 M distinct zipf(1.1) Int64 keys, SUM / MIN / MAX / AVG of one float64 column
@@ -435,8 +522,7 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
                                      group_capacity_hint=1_100_000).execute())[0]
     dt, prof, out = timed(ctx, torch, c4, 2, 1)
     entry("C4_groupby_zipf_1Mkeys_500M", r4, dt, prof, "qe_aggregate_static", BYTES_PER_ROW["c4"], len(b4),
-          {"groups": out.num_rows, "kernels_ms_per_step": {kk: vv["ms"] / 2 for kk, vv in prof.items()},
-           "note": "bound by LDS atomics and the partition pass, not by HBM: see kernels_ms_per_step"})
+          {"groups": out.num_rows, "note": "not HBM bound: see kernels_ms_per_step"}, steps=2)
     del zk, b4, out
 
     # The headline plan read straight off a Parquet file (uncompressed, PLAIN Float64 + dictionary Int64 key; 16 M
@@ -552,7 +638,29 @@ def cpu_baseline(rows, seed):
             reps2 += 1
     out["all_cores"] = {"value": n * reps2 / t2, "unit": "rows/s", "cores": threads,
                         "sample": f"{reps2} x {n} rows, row ranges over {threads} threads (ctypes releases the GIL), shard tables merged"}
+    out["reference_literal_aggregate"] = literal_aggregate_baseline(orc, k, c)
     return out
+
+
+def literal_aggregate_baseline(orc, k, v, rows=1_000_000):
+    """The reference's own aggregate loop (physical_plan/mod.rs:326-364: per distinct hash of a batch one membership mask
+    over the whole batch and one masked reduction per accumulator, O(rows x groups)), restated in oracle/qe_oracle.c, on
+    1 M rows of the synthetic table: MAX and MIN (the only aggregates the reference lowers, query_planner.rs:90-100) of a
+    float64 column, grouped by the 10-value key and by a 1000-value key derived from it.  One thread, one batch."""
+    res = {"rows": rows, "unit": "rows/s", "cores": 1, "kind": "port"}
+    rows = min(rows, len(k))
+    Cx = orc.ColumnExpression
+    for label, keys in (("groups_10", k[:rows]), ("groups_1000", (k[:rows] * 100 + (np.arange(rows) % 100)).astype(np.int64))):
+        chunk = orc.Chunk([orc.Array(orc.INT64, np.ascontiguousarray(keys)), orc.Array(orc.FLOAT64, np.ascontiguousarray(v[:rows]))])
+        reps, total, groups = 0, 0.0, 0
+        while total < 3.0 and reps < 5:
+            t0 = time.perf_counter()
+            got = list(orc.AggregateExec([orc.ScanExec([chunk])], [Cx(0)], [orc.MaxExpression(Cx(1)), orc.MinExpression(Cx(1))], literal=True).execute())[0]
+            total += time.perf_counter() - t0
+            reps += 1
+            groups = len(got.arrays[0].values)
+        res[label] = {"value": rows * reps / total, "groups": groups, "seconds_per_pass": total / reps}
+    return res
 
 
 if __name__ == "__main__":
