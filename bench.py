@@ -261,6 +261,7 @@ def main():
         result = step()
     barrier()
     dt = time.perf_counter() - t0
+    state_after = gpu_state(local_rank) if rank == 0 else None
     prof = ctx.profile_read()
     ctx.profile(False)
     # the merge alone (exchange + FINAL aggregate of one partial table), timed the same way: what N > 1 adds to a step
@@ -336,6 +337,7 @@ def main():
         "merge_ms_per_step": merge_ms,
     }
     out["config"]["topology"] = topology
+    out["gpu_state_after_timed_steps"] = state_after
 
     cols = result.columns()
     real = np.asarray(cols[2].values) > 0  # deferred mode pads the result to the table's slots
@@ -359,6 +361,23 @@ def main():
         print(json.dumps(out), flush=True)
     if multi:
         dist.destroy_process_group()
+
+
+def gpu_state(device=0):
+    """Clocks and power of the device as rocm-smi reports them right now (a child process; nothing here touches HIP):
+    recorded next to every timing, since the same kernel measures a few per cent apart from one session to the next."""
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(device), "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(r.stdout).values()))
+        keep = {}
+        for key, val in card.items():
+            low = key.lower()
+            if any(w in low for w in ("sclk", "mclk", "fclk", "socclk", "power", "junction")):
+                keep[key] = val
+        return keep
+    except Exception as e:  # rocm-smi missing or not answering: the numbers stand without it
+        return {"unavailable": str(e)[:200]}
 
 
 def measured_traffic(kernel_name, rows_per_launch):

@@ -155,3 +155,88 @@ def test_one_batch_past_2_to_31_rows(qe, torch_ctx):
     sk, sc = select(half, n)
     assert len(wc) == len(fc) + len(sc) == int((c > 0.999).sum())
     assert np.array_equal(wk, np.concatenate([fk, sk])) and np.array_equal(wc.view(np.uint64), np.concatenate([fc, sc]).view(np.uint64))
+
+
+def test_c4_zipf_1m_keys_500m(qe, torch_ctx):
+    """C4 at its full size: 500 M rows, 1 M zipf(1.1) Int64 keys, SUM / MIN / MAX / AVG / COUNT of one float64 column
+    through the high-cardinality path.  Keys and counts against torch.unique, sums against a torch scatter-add within
+    1e-12 of the magnitudes summed, minima / maxima bit for bit against torch scatter-reduce, the whole against the
+    merge of ragged parts, and the oracle on a prefix of the rows."""
+    torch, ctx = torch_ctx
+    n = 500_000_000
+    dev = torch.device("cuda", 0)
+    k = torch.empty(n, dtype=torch.int64, device=dev)
+    v = torch.empty(n, dtype=torch.float64, device=dev)
+    ctx.generate(2, 77, 0, n, 1_000_000, 1.1, k.data_ptr())
+    ctx.generate(0, 46, 0, n, 0.0, 1.0, v.data_ptr())
+    ctx.synchronize()
+    C = qe.ColumnExpression
+    aggs = lambda: [qe.SumExpression(C(1)), qe.MinExpression(C(1)), qe.MaxExpression(C(1)), qe.AvgExpression(C(1)), qe.CountExpression(None)]
+    step = 1 << 28
+
+    def plan(lo, hi, mode):
+        batches = [qe.Batch.from_torch(ctx, [k[s:min(hi, s + step)], v[s:min(hi, s + step)]]) for s in range(lo, hi, step)]
+        return qe.AggregateExec([qe.ScanExec(ctx, batches)], [C(0)], aggs(), mode=mode, group_capacity_hint=1_100_000)
+    print("c4: table generated", flush=True)
+    whole = by_key(list(plan(0, n, qe.AGG_MODE_SINGLE).execute())[0].columns())
+    keys, sums, mins, maxs, avgs, counts = whole
+    print("c4: aggregated", len(keys), flush=True)
+    uk, inv, cnt = torch.unique(k, return_inverse=True, return_counts=True)  # sorted keys
+    assert np.array_equal(keys, uk.cpu().numpy()) and np.array_equal(counts, cnt.cpu().numpy())
+    assert counts.sum() == n and len(keys) > 900_000
+    print("c4: torch.unique done", flush=True)
+    g = uk.shape[0]
+    # References.  torch's scatter reductions are one atomic per row on the group's address (a compare-swap loop for
+    # min / max): on the heaviest keys - tens of millions of rows on one address - they take minutes, and the rounding
+    # error of such a serial float64 sum is itself of the size of the tolerance.  So the 64 heaviest keys are checked
+    # against tree reductions over a mask (torch.sum / min / max), all other keys against the scatter reductions.
+    heavy = np.argsort(counts)[-64:]
+    zero = torch.zeros((), dtype=torch.float64, device=dev)
+    for i in heavy:
+        mine = k == int(keys[i])
+        tree = float(torch.where(mine, v, zero).sum())  # values are positive: the sum of magnitudes is the sum
+        assert abs(sums[i] - tree) <= REL * tree and abs(avgs[i] - tree / counts[i]) <= REL * tree / counts[i]
+        assert mins[i] == float(torch.where(mine, v, zero + 2.0).min()) and maxs[i] == float(torch.where(mine, v, zero - 1.0).max())
+    print("c4: heavy keys checked", flush=True)
+    is_heavy = torch.zeros(g, dtype=torch.bool, device=dev)
+    is_heavy[torch.from_numpy(heavy).to(dev)] = True
+    rows = ~is_heavy[inv]
+    inv_l, v_l = inv[rows], v[rows]
+    del rows
+    ref_sum = torch.zeros(g, dtype=torch.float64, device=dev).scatter_add_(0, inv_l, v_l).cpu().numpy()
+    ref_min = torch.full((g,), 2.0, dtype=torch.float64, device=dev).scatter_reduce_(0, inv_l, v_l, "amin").cpu().numpy()
+    ref_max = torch.full((g,), -1.0, dtype=torch.float64, device=dev).scatter_reduce_(0, inv_l, v_l, "amax").cpu().numpy()
+    light = np.ones(g, np.bool_)
+    light[heavy] = False
+    assert (np.abs(sums - ref_sum) <= 2 * REL * ref_sum)[light].all()  # scatter_add's order differs from ours: both within the bound
+    assert (np.abs(avgs - ref_sum / counts) <= 2 * REL * ref_sum / counts)[light].all()
+    assert np.array_equal(mins[light], ref_min[light]) and np.array_equal(maxs[light], ref_max[light])
+    del inv_l, v_l
+    del inv, uk, cnt
+    print("c4: sums, minima, maxima checked", flush=True)
+    # the whole = the FINAL merge of PARTIAL aggregates of ragged parts (PARTIAL splits AVG into sum and count)
+    cuts = [0, 99_999_999, 310_000_001, n]
+    parts = []
+    for lo, hi in zip(cuts, cuts[1:]):
+        parts += list(plan(lo, hi, qe.AGG_MODE_PARTIAL).execute())
+    merged = by_key(list(qe.final_plan(qe.ScanExec(ctx, parts), 1, aggs(), group_capacity_hint=1_100_000).execute())[0].columns())
+    assert np.array_equal(merged[0], keys) and np.array_equal(merged[5], counts)
+    assert np.array_equal(merged[2], mins) and np.array_equal(merged[3], maxs)
+    assert (np.abs(merged[1] - sums) <= 2 * REL * sums).all() and (np.abs(merged[4] - avgs) <= 2 * REL * avgs).all()
+    print("c4: merge of parts checked", flush=True)
+    # the oracle on a prefix (its single-pass aggregate): 2 M rows through the same high-cardinality path
+    m = 2_000_000
+    kh, vh = k[:m].cpu().numpy(), v[:m].cpu().numpy()
+    Co = orc.ColumnExpression
+    want = list(orc.AggregateExec([orc.ScanExec([orc.Chunk([orc.Array(orc.INT64, kh), orc.Array(orc.FLOAT64, vh)])])], [Co(0)],
+                                  [orc.SumExpression(Co(1)), orc.MinExpression(Co(1)), orc.MaxExpression(Co(1)), orc.AvgExpression(Co(1)),
+                                   orc.CountExpression(None)]).execute())[0].arrays
+    wo = np.argsort(want[0].values)
+    b = qe.Batch.from_torch(ctx, [k[:m], v[:m]])
+    got = by_key(list(qe.AggregateExec([qe.ScanExec(ctx, [b])], [C(0)], aggs(), group_capacity_hint=1_100_000).execute())[0].columns())
+    # oracle columns: key, SUM, MIN, MAX, AVG, COUNT - the same order as ours
+    assert np.array_equal(got[0], want[0].values[wo]) and np.array_equal(got[5], want[5].values[wo])
+    assert np.array_equal(got[2], want[2].values[wo]) and np.array_equal(got[3], want[3].values[wo])
+    osum = want[1].values[wo]
+    assert (np.abs(got[1] - osum) <= REL * osum).all()
+    assert (np.abs(got[4] - want[4].values[wo]) <= REL * osum / got[5]).all()
