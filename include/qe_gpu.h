@@ -307,6 +307,33 @@ qe_status qe_plan_execute(qe_plan *plan, qe_iter **out);
 qe_status qe_iter_next(qe_iter *iter, qe_batch **out);
 void qe_iter_free(qe_iter *iter);
 
+/* -------------------------------------------- selection without allocation */
+/* No counterpart in the reference.  For callers that cannot allocate device
+ * memory while they run - code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc: Selection(predicate) -> Projection(exprs) over
+ * one device-resident batch, the fused launch qe_plan_selection /
+ * qe_plan_projection / qe_iter_next make, with every output written into
+ * buffers the CALLER provides and the kernels' scratch (ticket counter, one
+ * look-back status word per tile) in a fixed array inside the library instead
+ * of a buffer from hipMalloc.  The call allocates no device memory, takes
+ * nothing from the context's pool and compiles nothing.
+ *   outs[i]: type = the expression's type (INT32 / INT64 / FLOAT64 / BOOLEAN),
+ *            memory_space = QE_MEM_DEVICE, values = the buffer, length = its
+ *            capacity in rows (at least the batch's rows: the number selected
+ *            is not known beforehand), validity = a bitmap buffer when the
+ *            expression can be null.  Bitmap buffers (boolean values, validity)
+ *            span whole 4-byte words: ((length + 31) / 32) * 4 bytes.
+ *   rows_out: the number of rows selected; rows keep their input order.
+ * Limits: at most QE_NOALLOC_MAX_ROWS rows per batch and 12 expressions that fit
+ * one kernel launch; no Utf8 / Timestamp columns or literals (their gathers and
+ * literal copies take buffers) - anything else is refused with an error, never
+ * served by allocating.  Every call on one GPU shares that GPU's array (1 MiB,
+ * held until the process ends): calls that overlap on one GPU race, whatever
+ * their contexts or streams.  Waits for the result (the row count). */
+#define QE_NOALLOC_MAX_ROWS (1ll << 29)
+qe_status qe_selection_noalloc(qe_context *ctx, const qe_batch *batch, const qe_expr *predicate, const qe_expr *const *exprs,
+                               int32_t n_exprs, const qe_column *outs, int64_t *rows_out);
+
 /* ------------------------------------------------- synthetic data (bench) */
 /* Counter-based generator (splitmix64 of row index and seed): fills
  * device buffers of `n` rows starting at global row `row0`, so any shard is

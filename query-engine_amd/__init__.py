@@ -108,6 +108,8 @@ ABI = {
     "qe_plan_execute": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "qe_iter_next": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "qe_iter_free": (None, [C.c_void_p]),
+    "qe_selection_noalloc": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(qe_column),
+                                         C.POINTER(C.c_int64)]),
     "qe_generate_column": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_double, C.c_double,
                                        C.c_void_p]),
     "qe_context_profile": (C.c_int32, [C.c_void_p, C.c_int32]),
@@ -426,6 +428,34 @@ class Batch:
             self.free()
         except Exception:
             pass
+
+
+NOALLOC_MAX_ROWS = 1 << 29  # QE_NOALLOC_MAX_ROWS
+
+
+def selection_noalloc(batch, predicate, exprs, outs):
+    """qe_selection_noalloc: Selection(predicate) -> Projection(exprs) over one device batch into buffers the caller
+    provides, with no device allocation inside the call.  outs: per expression a dict {type, values (device address),
+    length (capacity in rows), validity (device address or 0)}.  Returns the number of rows selected."""
+    hs = []
+    try:
+        ph = predicate._build()
+        hs.append(ph)
+        for e in exprs:
+            hs.append(e._build())
+        arr = (C.c_void_p * max(1, len(exprs)))(*[h.value for h in hs[1:]])
+        descs = (qe_column * max(1, len(outs)))()
+        for i, o in enumerate(outs):
+            d = descs[i]
+            d.type, d.memory_space, d.length = o["type"], MEM_DEVICE, o["length"]
+            d.values = o["values"]
+            d.validity = o.get("validity") or None
+        rows = C.c_int64()
+        _check(lib.qe_selection_noalloc(batch.ctx._h, batch._h, ph, arr, len(exprs), descs, C.byref(rows)))
+        return rows.value
+    finally:
+        for h in hs:
+            lib.qe_expr_free(h)
 
 
 # -------------------------------------------------------------- expressions

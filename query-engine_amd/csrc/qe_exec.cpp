@@ -1573,6 +1573,26 @@ static std::string describe_launch(JitKind kind, const SpecFields &f) {
 
 }  // namespace qe
 
+// ------------------------------------------------- scratch of the no-alloc entry point
+// qe_selection_noalloc runs the selection kernels without taking any device memory: their scratch
+// (ticket counter, result words, one look-back status word per tile) lives in this array instead of a
+// buffer from hipMalloc.  Every GPU holds its own copy at its own address until the process ends; the
+// array's name is only a handle for hipGetSymbolAddress, host code uses the pointer that call returns.
+constexpr int64_t NOALLOC_MAX_ROWS = QE_NOALLOC_MAX_ROWS;
+constexpr size_t NOALLOC_SCRATCH_WORDS = sizeof(qe::FilterScratch) / 8 + (size_t)(NOALLOC_MAX_ROWS / qe::FILTER_TILE_ROWS) + 8;
+static __device__ __align__(256) unsigned long long qe_noalloc_scratch[NOALLOC_SCRATCH_WORDS];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static unsigned long long *g_noalloc_ptr[NOALLOC_MAX_DEVICES];  // per device: where its copy of the array lives
+
+// Once per device, with that device current (qe_context_create).
+static void noalloc_scratch_setup(int device) {
+  if (device < 0 || device >= NOALLOC_MAX_DEVICES || g_noalloc_ptr[device]) return;
+  void *ptr = nullptr;
+  hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(qe_noalloc_scratch));
+  if (e != hipSuccess || !ptr) qe::fail(QE_ERR_DEVICE, std::string("hipGetSymbolAddress(qe_noalloc_scratch): ") + hipGetErrorString(e));
+  g_noalloc_ptr[device] = (unsigned long long *)ptr;
+}
+
 // ==================================================================== C ABI
 using namespace qe;
 
@@ -1694,6 +1714,7 @@ qe_status qe_context_create(int32_t device, void *stream, qe_context **out) {
       QE_HIP(hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking));
       ctx->c.own_stream = true;
     }
+    noalloc_scratch_setup(device);
     *out = ctx.release();
   });
 }
@@ -2224,6 +2245,93 @@ qe_status qe_iter_next(qe_iter *iter, qe_batch **out) {
 }
 
 void qe_iter_free(qe_iter *iter) { delete iter; }
+
+// ------------------------------------------------------ no-alloc selection
+static bool expr_needs_device_memory(const ExprPtr &e, const Batch &in) {
+  // utf8 literals are copied to the device, utf8 / timestamp columns take gather passes with buffers of their own
+  if (!e) return false;
+  if (e->kind == EK_LITERAL) return e->type == QE_TYPE_UTF8;
+  if (e->kind == EK_COLUMN)
+    return e->index >= 0 && e->index < (int)in.cols.size() && (in.cols[e->index].type == QE_TYPE_UTF8 || in.cols[e->index].type == QE_TYPE_TIMESTAMP_NS);
+  return expr_needs_device_memory(e->l, in) || expr_needs_device_memory(e->r, in);
+}
+
+qe_status qe_selection_noalloc(qe_context *ctx, const qe_batch *batch, const qe_expr *predicate, const qe_expr *const *exprs,
+                               int32_t n_exprs, const qe_column *outs, int64_t *rows_out) {
+  return guarded([&] {
+    QE_REQUIRE(ctx && batch && predicate && rows_out && n_exprs >= 1 && exprs && outs, "bad arguments");
+    *rows_out = 0;
+    Context *c = &ctx->c;
+    c->bind();
+    const int64_t n = batch->b.rows;
+    if (n > NOALLOC_MAX_ROWS)
+      fail(QE_ERR_INVALID_ARGUMENT, "qe_selection_noalloc: " + std::to_string(n) + " rows exceed the maximum of " +
+                                        std::to_string(NOALLOC_MAX_ROWS) + " (QE_NOALLOC_MAX_ROWS) its fixed scratch array serves");
+    if (n_exprs > VM_MAX_OUTS) fail(QE_ERR_INVALID_ARGUMENT, "qe_selection_noalloc: at most " + std::to_string(VM_MAX_OUTS) + " output expressions");
+    unsigned long long *scratch_words = (c->device >= 0 && c->device < NOALLOC_MAX_DEVICES) ? g_noalloc_ptr[c->device] : nullptr;
+    if (!scratch_words) fail(QE_ERR_DEVICE, "qe_selection_noalloc: no scratch array on this device");
+    for (auto &col : batch->b.cols)
+      if (col.space != QE_MEM_DEVICE) fail(QE_ERR_INVALID_ARGUMENT, "batches must be device resident (qe_batch_to_device)");
+    Batch in = without_redundant_validity(batch->b);
+    Schema schema = schema_of(in);
+    ExprPtr pred = expr_normalize(predicate->e, c->flags);
+    if (expr_type(pred, schema) != QE_TYPE_BOOLEAN)
+      fail(QE_ERR_NO_BOOLEAN_ARRAY_FOR_FILTER, "Expr doesn't evaluate to a boolean array, which is needed to filter.");
+    if (pred->kind == EK_LITERAL && !pred->valid) fail(QE_ERR_SCALAR_TO_ARRAY, "Couldn't convert Scalar value `null` to array.");
+    std::vector<ExprPtr> es;
+    std::vector<int> types, vm_list;
+    ExprFitter fitter{c, in, schema};
+    if (expr_needs_device_memory(pred, in) || fitter.over(pred))
+      fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "qe_selection_noalloc: the predicate needs device memory of its own (utf8, or too large for one kernel)");
+    for (int i = 0; i < n_exprs; ++i) {
+      QE_REQUIRE(exprs[i], "expr is null");
+      ExprPtr e = expr_normalize(exprs[i]->e, c->flags);
+      const int t = expr_type(e, schema);
+      if (e->kind == EK_LITERAL && !e->valid) fail(QE_ERR_SCALAR_TO_ARRAY, "Couldn't convert Scalar value `null` to array.");
+      if (expr_needs_device_memory(e, in) || t == QE_TYPE_UTF8 || fitter.over(e))
+        fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "qe_selection_noalloc: output " + std::to_string(i) + " needs device memory of its own (utf8, timestamp, or too large for one kernel)");
+      const qe_column &o = outs[i];
+      if (o.type != t) fail(QE_ERR_INVALID_ARGUMENT, "qe_selection_noalloc: output " + std::to_string(i) + " has type " + type_name(o.type) + ", the expression gives " + type_name(t));
+      if (o.memory_space != QE_MEM_DEVICE || !o.values) fail(QE_ERR_INVALID_ARGUMENT, "qe_selection_noalloc: output buffers must be device memory");
+      if (o.length < n) fail(QE_ERR_INVALID_ARGUMENT, "qe_selection_noalloc: output " + std::to_string(i) + " holds " + std::to_string(o.length) + " rows, the batch has " + std::to_string(n));
+      if (expr_nullable(e, schema) && !o.validity) fail(QE_ERR_INVALID_ARGUMENT, "qe_selection_noalloc: output " + std::to_string(i) + " can be null and needs a validity buffer");
+      if (((uintptr_t)o.values & (t == QE_TYPE_INT32 || t == QE_TYPE_BOOLEAN ? 3u : 7u)) || ((uintptr_t)o.validity & 3u))
+        fail(QE_ERR_INVALID_ARGUMENT, "qe_selection_noalloc: output buffers must be aligned to their element (bitmaps: 4 bytes)");
+      es.push_back(e);
+      types.push_back(t);
+      vm_list.push_back(i);
+    }
+    if (n == 0) return;
+    Compiler comp(c, &in);
+    FilterArgs args{};
+    const size_t placed = lower_filter(comp, schema, pred, es, types, vm_list, 0, n, nullptr, args, [&](int i, bool nullable, VmOut &o) {
+      o.values = const_cast<void *>(outs[i].values);
+      o.validity = nullable ? (uint32_t *)const_cast<void *>(outs[i].validity) : nullptr;
+    });
+    if (placed != vm_list.size() || !comp.keepalive.empty())
+      fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "qe_selection_noalloc: the expressions do not fit one kernel launch");
+    // bitmaps are written with atomic ORs into whole words: they start out zero
+    const size_t words_bytes = (size_t)((n + 31) / 32) * 4;
+    for (int i = 0; i < n_exprs; ++i) {
+      if (types[i] == QE_TYPE_BOOLEAN) QE_HIP(hipMemsetAsync(const_cast<void *>(outs[i].values), 0, words_bytes, c->stream));
+      if (args.outs[i].validity) QE_HIP(hipMemsetAsync(args.outs[i].validity, 0, words_bytes, c->stream));
+    }
+    FilterScratch *scratch = (FilterScratch *)scratch_words;
+    args.scratch = scratch;
+    QE_HIP(launch_filter_reset(scratch, n, c->stream));  // the array keeps the last call's tickets and status words
+    DeviceInfo dev = c->dev;
+    dev.jit = JIT_OFF;  // compiling a kernel loads a code object: device memory
+    const char *kname = "qe_filter_kernel";
+    c->prof_begin(kname, n);
+    QE_HIP(launch_filter(args, dev, c->stream, &kname));
+    c->prof_end(kname);
+    unsigned long long result[3] = {0, 0, 0};
+    QE_HIP(hipMemcpyAsync(result, scratch, sizeof(result), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    if (result[2] != 0) fail(QE_ERR_INTERNAL, "filter look-back timed out");
+    *rows_out = (int64_t)result[1];
+  });
+}
 
 // ----------------------------------------------------------------- utilities
 qe_status qe_generate_column(qe_context *ctx, int32_t kind, uint64_t seed, int64_t row0, int64_t n, double lo, double hi,

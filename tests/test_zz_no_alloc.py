@@ -1,0 +1,117 @@
+"""qe_selection_noalloc (Selection -> Projection into caller-provided buffers, kernel scratch in a fixed array inside the
+library, no device allocation) against the existing entry points (qe_plan_selection / qe_plan_projection / qe_iter_next)
+on the same batches: bit for bit, two calls in a row, the second on a smaller input - the array keeps what the first
+call left in it.  No counterpart in the reference."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _table(n, seed):
+    r = np.random.default_rng(seed)
+    k = r.integers(-5, 5, n).astype(np.int64)
+    a, b, c = r.uniform(-1, 1, n), r.uniform(-1, 1, n), r.uniform(0, 1, n)
+    i32 = r.integers(-1000, 1000, n).astype(np.int32)
+    nullable = (r.uniform(-1, 1, n), r.uniform(0, 1, n) > 0.2)  # float64 with nulls
+    return [k, a, b, c, i32, nullable]
+
+
+def _exprs(qe):
+    C = qe.ColumnExpression
+    pred = qe.AndExpression(qe.GtExpression(C(3), qe.LiteralFloatExpression(0.5)), qe.NeqExpression(C(0), qe.LiteralInt64Expression(2)))
+    outs = [C(0),                                                        # int64 pass-through
+            qe.AddExpression(C(1), qe.MulExpression(C(2), C(3))),        # float64
+            qe.MulExpression(C(4), qe.LiteralIntegerExpression(3)),      # int32
+            qe.LtExpression(C(1), C(2)),                                 # boolean (bitmap output)
+            qe.AddExpression(C(5), C(1))]                                # float64, nullable (validity bitmap output)
+    types = [qe.TYPE_INT64, qe.TYPE_FLOAT64, qe.TYPE_INT32, qe.TYPE_BOOLEAN, qe.TYPE_FLOAT64]
+    return pred, outs, types
+
+
+def _reference_path(qe, ctx, batch):
+    pred, outs, _ = _exprs(qe)
+    got = list(qe.ProjectionExec([qe.SelectionExec([qe.ScanExec(ctx, [batch])], pred)], outs).execute())
+    return got[0].columns()
+
+
+def _noalloc_path(qe, torch, batch, n, poison):
+    pred, outs, types = _exprs(qe)
+    words = (n + 31) // 32
+    bufs, descs = [], []
+    for t in types:
+        if t == qe.TYPE_BOOLEAN:
+            v = torch.full((max(words, 1),), poison, dtype=torch.int32, device="cuda")
+        else:
+            v = torch.full((max(n, 1),), poison, dtype={qe.TYPE_INT64: torch.int64, qe.TYPE_FLOAT64: torch.float64, qe.TYPE_INT32: torch.int32}[t], device="cuda")
+        bufs.append(v)
+        descs.append({"type": t, "values": v.data_ptr(), "length": n})
+    valid = torch.full((max(words, 1),), poison, dtype=torch.int32, device="cuda")
+    descs[4]["validity"] = valid.data_ptr()
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    m = qe.selection_noalloc(batch, pred, outs, descs)
+    assert torch.cuda.memory_allocated() == before
+    torch.cuda.synchronize()
+
+    def bits(t):
+        return np.unpackbits(t.cpu().numpy().view(np.uint8), bitorder="little")[:m].astype(np.bool_)
+    cols = [bufs[0][:m].cpu().numpy(), bufs[1][:m].cpu().numpy(), bufs[2][:m].cpu().numpy(), bits(bufs[3]), bufs[4][:m].cpu().numpy()]
+    return m, cols, bits(valid)
+
+
+@pytest.mark.parametrize("sizes", [(300_000, 70_001), (8192, 1), (100_000, 0)])
+def test_noalloc_selection_matches_plan_path_twice(qe, sizes):
+    import torch
+    torch.cuda.set_device(0)
+    ctx = qe.Context(0)
+    try:
+        for call, n in enumerate(sizes):  # the second call is smaller: nothing of the first may show through
+            table = _table(n, seed=11 + call)
+            batch = qe.Batch.from_numpy(ctx, table)
+            want = _reference_path(qe, ctx, batch) if n else None
+            m, got, got_valid = _noalloc_path(qe, torch, batch, n, poison=-1 if call == 0 else 0x5A5A5A5A)
+            if n == 0:
+                assert m == 0
+                continue
+            assert m == len(want[0].values)
+            for i in range(4):
+                assert np.array_equal(np.asarray(got[i]).view(np.uint8), np.asarray(want[i].values).view(np.uint8)), f"call {call}, output {i}"
+            wv = want[4].validity if want[4].validity is not None else np.ones(m, np.bool_)
+            assert np.array_equal(got_valid, wv)
+            assert np.array_equal(got[4].view(np.uint64)[wv], np.asarray(want[4].values).view(np.uint64)[wv])
+            # and against numpy directly: order-preserving selection
+            k, a, b, c = table[0], table[1], table[2], table[3]
+            keep = (c > 0.5) & (k != 2)
+            assert m == int(keep.sum()) and np.array_equal(got[0], k[keep]) and np.array_equal(got[1], (a + b * c)[keep])
+    finally:
+        ctx.close()
+
+
+def test_noalloc_rejects_what_it_cannot_serve(qe):
+    import torch
+    ctx = qe.Context(0)
+    try:
+        n = 1000
+        batch = qe.Batch.from_numpy(ctx, [np.arange(n, dtype=np.int64), ["x"] * n])
+        C = qe.ColumnExpression
+        out = torch.zeros(n, dtype=torch.int64, device="cuda")
+        ok = [{"type": qe.TYPE_INT64, "values": out.data_ptr(), "length": n}]
+        pred = qe.GtExpression(C(0), qe.LiteralInt64Expression(10))
+        assert qe.selection_noalloc(batch, pred, [C(0)], ok) == n - 11
+        with pytest.raises(qe.QeError) as e:  # output too small for the batch
+            qe.selection_noalloc(batch, pred, [C(0)], [{"type": qe.TYPE_INT64, "values": out.data_ptr(), "length": n - 1}])
+        assert e.value.name == "InvalidArgument"
+        with pytest.raises(qe.QeError) as e:  # utf8 predicate: its literal would be copied to the device
+            qe.selection_noalloc(batch, qe.EqExpression(C(1), qe.LiteralStringExpression("x")), [C(0)], ok)
+        assert e.value.name == "PhysicalExpressionNotSuported"
+        with pytest.raises(qe.QeError) as e:  # wrong output type
+            qe.selection_noalloc(batch, pred, [C(0)], [{"type": qe.TYPE_FLOAT64, "values": out.data_ptr(), "length": n}])
+        assert e.value.name == "InvalidArgument"
+        # the size limit is checked against the batch's row count before anything is launched
+        big = qe.Batch.from_device_columns(ctx, [{"type": qe.TYPE_INT64, "length": qe.NOALLOC_MAX_ROWS + 1, "values": out.data_ptr()}])
+        with pytest.raises(qe.QeError) as e:
+            qe.selection_noalloc(big, pred, [C(0)], [{"type": qe.TYPE_INT64, "values": out.data_ptr(), "length": qe.NOALLOC_MAX_ROWS + 1}])
+        assert e.value.name == "InvalidArgument" and "exceed the maximum" in e.value.message
+    finally:
+        ctx.close()
