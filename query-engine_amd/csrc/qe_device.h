@@ -757,6 +757,7 @@ struct LdsTable {
   uint32_t *rowcnt;          // [cap + 1]
   uint32_t *nn;              // [n_accs][cap + 1]
   uint32_t *used;            // claimed slots
+  uint16_t *door;            // high-cardinality mode: tags of keys seen once (see lds_find_or_claim4); nullptr = none
   uint32_t cap;
   uint32_t stride;           // cap + 1
   uint32_t limit;
@@ -849,50 +850,73 @@ __device__ __forceinline__ int32_t lds_find_or_claim(const LdsTable &L, uint64_t
   return -1;
 }
 
-// The hot case of the lookup: the key already sits in, or right after, its home slot.  Read-only
-// probes of the lane's four rows, issued together probe by probe (four independent LDS reads in
-// flight instead of a serial chain per row).  Outcome per row:
-//   slot >= 0      found
-//   SLOT_PENDING   an empty slot came first: the key is not in the table and may be claimable,
-//                  or FAST_PROBES slots held other keys: the full lookup decides
-//   SLOT_LDS_MISS  (only when `table_full`) the key is not among the first FAST_PROBES slots or an
-//                  empty slot came first: nothing can be claimed any more, so this is final
-constexpr int32_t SLOT_PENDING = INT32_MIN + 1;
-constexpr int FAST_PROBES = 3;
-__device__ __forceinline__ void lds_probe_fast(const LdsTable &L, const uint64_t (&key)[VM_R], uint32_t rows, bool table_full,
-                                               int32_t (&slot)[VM_R]) {
+// The lookup of the lane's four rows, all at once: every probe round has the four LDS reads in flight together (a
+// serial chain per row costs four LDS round trips per probe), and a key that meets an empty slot claims it there and
+// then (compare-swap) unless the table has stopped taking keys.  Rows whose key is not found within `max_probes`
+// slots, or not in a table that takes no more keys, come back as SLOT_LDS_MISS: their rows need another home (the
+// global table, or the row log in high-cardinality mode - where giving up early is always allowed, because a logged row
+// is aggregated all the same).
+constexpr int SPILL_MODE_PROBES = 4;
+constexpr uint32_t DOOR_ENTRIES = 4096;  // 16-bit tags
+__device__ __forceinline__ void lds_find_or_claim4(const LdsTable &L, const uint64_t (&key)[VM_R], uint32_t rows, int max_probes,
+                                                   int32_t (&slot)[VM_R]) {
+  const uint32_t mask = L.cap - 1;
   uint32_t h[VM_R];
   uint32_t open = rows;  // rows still looking
 #pragma unroll
   for (int j = 0; j < VM_R; ++j) {
-    h[j] = hash32(key[j]) & (L.cap - 1);
-    slot[j] = ((rows >> j) & 1u) ? (table_full ? SLOT_LDS_MISS : SLOT_PENDING) : SLOT_NONE;
-    // the key equal to the empty marker lives in the reserved slot: full lookup
+    h[j] = hash32(key[j]) & mask;
+    slot[j] = ((rows >> j) & 1u) ? SLOT_LDS_MISS : SLOT_NONE;
     if (((rows >> j) & 1u) && key[j] == AGG_EMPTY_KEY) {
-      slot[j] = SLOT_PENDING;
+      // the one key equal to the empty marker lives in the reserved slot
+      (void)atomicCAS(&L.keys[L.cap], AGG_EMPTY_KEY, 0ull);
+      slot[j] = (int32_t)L.cap;
       open &= ~(1u << j);
     }
   }
-#pragma unroll
-  for (int d = 0; d < FAST_PROBES; ++d) {
+#pragma unroll 1
+  for (int p = 0; p < max_probes; ++p) {
+    if (__ballot(open != 0) == 0) break;
     unsigned long long cur[VM_R];
 #pragma unroll
     for (int j = 0; j < VM_R; ++j) {
       cur[j] = AGG_EMPTY_KEY;
-      if ((open >> j) & 1u) cur[j] = *(volatile unsigned long long *)&L.keys[(h[j] + d) & (L.cap - 1)];
+      if ((open >> j) & 1u) cur[j] = *(volatile unsigned long long *)&L.keys[h[j]];
     }
 #pragma unroll
     for (int j = 0; j < VM_R; ++j) {
-      if ((open >> j) & 1u) {
-        if (cur[j] == key[j]) {
-          slot[j] = (int32_t)((h[j] + d) & (L.cap - 1));
-          open &= ~(1u << j);
-        } else if (cur[j] == AGG_EMPTY_KEY) {
-          open &= ~(1u << j);  // not in the table; slot[j] already says what that means
+      // (every array element is written once, by a select at this level: stores to slot[] / h[] from inside the branches
+      // get merged into one store with a computed index, and the arrays end up in scratch memory)
+      const bool is_open = ((open >> j) & 1u) != 0;
+      const bool hit = is_open && cur[j] == key[j];
+      bool got = hit, closed = hit;
+      if (is_open && cur[j] == AGG_EMPTY_KEY) {
+        // an empty slot ends the probe sequence: the key is not in the table.  Claim the slot if the table still takes keys.
+        closed = true;
+        bool admit = *(volatile uint32_t *)L.used < L.limit;
+        if (admit && L.door) {
+          // Admission by second sighting.  When rows that find no slot are logged anyway, a slot is worth having only
+          // for a key that comes often, and with many distinct keys most first sightings are of keys that never
+          // come again: a key is let in when its tag is still in a small direct-mapped table of recent sightings.
+          const uint32_t hf = hash32(key[j]);  // (again: rare, and registers held across the loop cost more)
+          const uint32_t d = (hf >> 12) & (DOOR_ENTRIES - 1);
+          const uint16_t tag = (uint16_t)((hf >> 16) | 1u);
+          if (*(volatile uint16_t *)&L.door[d] != tag) {
+            L.door[d] = tag;
+            admit = false;
+          }
+        }
+        if (admit) {
+          const unsigned long long old = atomicCAS(&L.keys[h[j]], AGG_EMPTY_KEY, (unsigned long long)key[j]);
+          if (old == AGG_EMPTY_KEY) atomicAdd(L.used, 1u);
+          got = old == AGG_EMPTY_KEY || old == key[j];
+          closed = got;  // else another key took the slot in the meantime: the sequence goes on
         }
       }
+      slot[j] = got ? (int32_t)h[j] : slot[j];
+      h[j] = (is_open && !closed) ? ((h[j] + 1) & mask) : h[j];
+      open = closed ? (open & ~(1u << j)) : open;
     }
-    if (d + 1 < FAST_PROBES && __ballot(open != 0) == 0) break;
   }
 }
 
@@ -950,6 +974,7 @@ __device__ __forceinline__ void agg_lds_setup(LdsTable &L, unsigned long long *l
   L.rowcnt = (uint32_t *)(L.acc + (size_t)n_accs * L.stride);
   L.nn = with_nn ? L.rowcnt + L.stride : nullptr;
   L.used = L.rowcnt + L.stride + (with_nn ? (size_t)n_accs * L.stride : 0);
+  L.door = nullptr;
 }
 
 struct AggRows {
@@ -996,7 +1021,9 @@ __device__ __forceinline__ void spill_values(const SpillState &sp, uint32_t col,
 }
 
 // Finds / claims the group slot of every active row and counts the rows in.
-template <bool TRY_LEADER = true>
+// ROLLED: the rows are looked up one after the other by a rolled loop - far fewer registers than the four-at-once
+// lookup, for kernels in which lookups are the exception (narrow rows, where the registers decide how many waves fit).
+template <bool TRY_LEADER = true, bool ROLLED = false>
 __device__ __forceinline__ void agg_lookup(const LdsTable &L, const AggTable &T, uint32_t active, uint32_t lane, AggRows &G,
                                            SpillState &sp) {
   uint32_t rem = active;
@@ -1030,33 +1057,21 @@ __device__ __forceinline__ void agg_lookup(const LdsTable &L, const AggTable &T,
     ball &= ~__ballot(mb != 0);  // next candidate: a lane none of whose rows matched
   }
   rem &= ~lead_mb;
-  // ---- LDS slots.  First the cheap probe of every row's home slot (and of the dominant key's,
-  // by every lane: the value is wave-uniform), then the full lookup for what that left over.
+  // ---- LDS slots of the rows (claiming as they go), and of the dominant key (one lane looks it up for the wave)
   int32_t lsl = SLOT_NONE;
-  {
-    const uint32_t hl = hash32(k0) & (L.cap - 1);
-    unsigned long long curl = AGG_EMPTY_KEY;
-    if (lead_cnt != 0) curl = *(volatile unsigned long long *)&L.keys[hl];
-    // once the table has stopped accepting keys a failed probe is final in high-cardinality mode
-    // (the row is logged); otherwise the full lookup may still claim a slot or reach further
-    const bool table_full = sp.keys != nullptr && *(volatile uint32_t *)L.used >= L.limit;
-    lds_probe_fast(L, G.key, rem, table_full, G.slot);
-    if (lead_cnt != 0 && (int)lane == src) lsl = (curl == k0 && k0 != AGG_EMPTY_KEY) ? (int32_t)hl : SLOT_PENDING;
-  }
-  uint32_t pend = 0;
-#pragma unroll
-  for (int j = 0; j < VM_R; ++j)
-    if (G.slot[j] == SLOT_PENDING) pend |= 1u << j;
-  if (__ballot(pend != 0 || lsl == SLOT_PENDING) != 0) {
-    if (lsl == SLOT_PENDING) lsl = lds_find_or_claim(L, k0);
+  if constexpr (ROLLED) {
+    uint32_t pend = rem;
 #pragma unroll 1
     for (int it = 0; it < VM_R; ++it) {
-      if (pend & 1u) G.slot[0] = lds_find_or_claim(L, G.key[0]);
+      G.slot[0] = (pend & 1u) ? lds_find_or_claim(L, G.key[0]) : SLOT_NONE;  // -1 = SLOT_LDS_MISS
       pend = rot4(pend);
       QE_ROT4(G.key);
       QE_ROT4(G.slot);
     }
+  } else {
+    lds_find_or_claim4(L, G.key, rem, sp.keys != nullptr ? SPILL_MODE_PROBES : LDS_MAX_PROBE, G.slot);
   }
+  if (lead_cnt != 0 && (int)lane == src) lsl = lds_find_or_claim(L, k0);
   // ---- keys the LDS table has no room for go to the global table (rare: rolled loop)
   uint32_t miss = 0;
 #pragma unroll
@@ -1222,6 +1237,8 @@ __device__ __forceinline__ void agg_lds_clear(const LdsTable &L, const VmAcc *ac
       if (L.nn) L.nn[a * L.stride + i] = 0;
     }
   }
+  if (L.door)
+    for (uint32_t i = threadIdx.x; i < DOOR_ENTRIES; i += blockDim.x) L.door[i] = 0;
   if (threadIdx.x == 0) *L.used = 0;
   __syncthreads();
 }

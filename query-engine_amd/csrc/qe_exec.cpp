@@ -849,8 +849,15 @@ static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &b
     }
     sp.acc_col[i] = (uint8_t)col;
   }
+  // Rows will miss the workgroups' tables in numbers: when a kernel specialised for the shape exists, one wide workgroup
+  // per compute unit with a table of four times the slots (fewer rows in the log, the same waves in flight)
+  if (aggregate_wide_available(args, ctx->dev)) {
+    args.block_threads = AGG_WIDE_THREADS;
+    args.lds_cap = aggregate_lds_slots(args, ctx->dev, 0, true);
+    args.lds_limit = args.lds_cap - args.lds_cap / 4;
+  }
   const int grid = aggregate_grid(args, ctx->dev);
-  sp.waves = grid * VM_BLOCK_WAVES;
+  sp.waves = grid * (int)((args.block_threads ? args.block_threads : (uint32_t)VM_BLOCK_THREADS) / 64);
   const int64_t nsteps = (args.n_rows + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
   const int64_t steps_per_wave = (nsteps + sp.waves - 1) / sp.waves;
   AggSpill &a = args.spill;
@@ -868,42 +875,70 @@ static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &b
   return sp;
 }
 
-// Second phase: partition the log by key hash, aggregate partition by partition.
+// Second phase: partition the log by key hash (count, scan, one or two scatter passes), aggregate partition by partition.
 static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &args, int64_t group_hint) {
-  // partitions: as few as keep a partition's distinct keys within 5/8 of the LDS table of the second
-  // phase (fewer partitions mean deeper stages and longer bursts in the move)
+  // partitions: as few as keep a partition's distinct keys within 5/8 of the LDS table of the second phase
   const int64_t keys_per_partition = (int64_t)partitioned_lds_slots(args.n_accs) * 5 / 8;
-  int bits = 6;
+  // (and no fewer than 256: a partition is one workgroup's work, and every compute unit should have some)
+  int bits = 8;
   while (bits < 11 && ((int64_t)1 << bits) * keys_per_partition < group_hint) ++bits;
+  static int forced_bits = [] {
+    const char *e = getenv("QE_SPILL_BITS");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced_bits >= 1 && forced_bits <= 11 && forced_bits >= bits) bits = forced_bits;
   static int forced_blocks = [] {
     const char *e = getenv("QE_SPILL_BLOCKS");
     return e ? atoi(e) : 0;
   }();
   const int blocks = forced_blocks > 0 ? forced_blocks : ctx->dev.cus;
-  const size_t cells = spill_cells(bits, blocks);
+  const int bits1 = spill_level1_bits(bits);
+  const size_t cells = spill_cells(bits, blocks), cells1 = spill_cells(bits1, blocks);
   BufferPtr cell_buf = device_buffer(ctx, (cells + 1) * 4 + 64);
+  BufferPtr cell1_buf = device_buffer(ctx, (cells1 + 1) * 4 + 64);
   BufferPtr scan_buf = device_buffer(ctx, scan_scratch_elems((int64_t)cells) * 4 + 64);
-  int32_t *cell = (int32_t *)cell_buf->ptr;
+  int32_t *cell = (int32_t *)cell_buf->ptr, *cell1 = (int32_t *)cell1_buf->ptr;
   unsigned long long *total = ctx->counters + 2;
   QE_HIP(hipMemsetAsync(total, 0, 2 * sizeof(unsigned long long), ctx->stream));
   ctx->prof_begin("qe_spill_count_kernel");
-  QE_HIP(launch_spill_partition(args.spill, sp.waves, bits, blocks, false, cell, nullptr, nullptr, total, ctx->stream));
+  QE_HIP(launch_spill_count(args.spill, sp.waves, bits, blocks, cell, total, ctx->stream));
   ctx->prof_end();
+  if (bits1 < bits) {
+    QE_HIP(launch_spill_cells_level1(cell, cell1, bits, blocks, ctx->stream));
+    QE_HIP(launch_exclusive_scan_i32(cell1, (int64_t)cells1, (int32_t *)scan_buf->ptr, ctx->stream));
+  }
   QE_HIP(launch_exclusive_scan_i32(cell, (int64_t)cells, (int32_t *)scan_buf->ptr, ctx->stream));
   QE_HIP(hipMemcpyAsync(ctx->host_counters + 2, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   ctx->sync();
   const int64_t m = (int64_t)ctx->host_counters[2];
   if (m == 0) return;
-  BufferPtr out_keys = device_buffer(ctx, (size_t)m * 8 + 64);
-  BufferPtr out_vals = device_buffer(ctx, args.spill.capacity * 8 * args.spill.n_inputs + 64);
-  ctx->prof_begin("qe_spill_move_kernel");
-  QE_HIP(launch_spill_partition(args.spill, sp.waves, bits, blocks, true, cell, (unsigned long long *)out_keys->ptr,
-                                (unsigned long long *)out_vals->ptr, total, ctx->stream));
-  ctx->prof_end();
+  const uint64_t stride = ((uint64_t)m + 63) & ~63ull;  // rows between the value columns of a partitioned copy
+  const uint32_t n_in = args.spill.n_inputs;
+  BufferPtr out_keys = device_buffer(ctx, stride * 8 + 64);
+  BufferPtr out_vals = device_buffer(ctx, stride * 8 * n_in + 64);
+  if (bits1 < bits) {
+    BufferPtr mid_keys = device_buffer(ctx, stride * 8 + 64);
+    BufferPtr mid_vals = device_buffer(ctx, stride * 8 * n_in + 64);
+    ctx->prof_begin("qe_spill_scatter_kernel (level 1)");
+    QE_HIP(launch_spill_scatter(args.spill, sp.waves, 1, bits1, bits1, blocks, nullptr, nullptr, 0, nullptr, m, cell1,
+                                (unsigned long long *)mid_keys->ptr, (unsigned long long *)mid_vals->ptr, stride, ctx->stream));
+    ctx->prof_end();
+    ctx->prof_begin("qe_spill_scatter_kernel (level 2)");
+    QE_HIP(launch_spill_scatter(args.spill, sp.waves, 2, bits, bits1, blocks, (const unsigned long long *)mid_keys->ptr,
+                                (const unsigned long long *)mid_vals->ptr, stride, cell1, m, cell, (unsigned long long *)out_keys->ptr,
+                                (unsigned long long *)out_vals->ptr, stride, ctx->stream));
+    ctx->prof_end();
+    // (the middle copy goes back to the pool here: later users are ordered behind these kernels on the stream)
+  } else {
+    ctx->prof_begin("qe_spill_scatter_kernel");
+    QE_HIP(launch_spill_scatter(args.spill, sp.waves, 1, bits, bits, blocks, nullptr, nullptr, 0, nullptr, m, cell,
+                                (unsigned long long *)out_keys->ptr, (unsigned long long *)out_vals->ptr, stride, ctx->stream));
+    ctx->prof_end();
+  }
   PartArgs pa{};
   pa.keys = (const unsigned long long *)out_keys->ptr;
   pa.vals = (const unsigned long long *)out_vals->ptr;
-  pa.capacity = args.spill.capacity;
+  pa.capacity = stride;
   pa.offsets = cell;
   pa.n_parts = 1 << bits;
   pa.stride = blocks;
@@ -913,7 +948,7 @@ static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &
     pa.acc_col[i] = sp.acc_col[i];
   }
   pa.n_accs = args.n_accs;
-  pa.n_inputs = (int)args.spill.n_inputs;
+  pa.n_inputs = (int)n_in;
   pa.table = args.table;
   pa.lds_cap = partitioned_lds_slots(args.n_accs);
   pa.lds_limit = pa.lds_cap - pa.lds_cap / 4;
@@ -1107,7 +1142,7 @@ struct AggState {
     lower_aggregate(comp, schema, pred_n, bspec, spec, args);
     args.table = table;
     args.n_rows = in.rows;
-    args.lds_cap = aggregate_lds_slots(args.n_accs, ctx->dev, effective_hint());
+    args.lds_cap = aggregate_lds_slots(args, ctx->dev, effective_hint(), false);
     args.lds_limit = args.lds_cap - args.lds_cap / 4;
     SpillPlan sp = plan_spill(ctx, schema, bspec, args, effective_hint());
     const char *kname = "qe_aggregate_kernel";

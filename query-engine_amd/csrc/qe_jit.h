@@ -26,6 +26,10 @@ enum JitKind : int { JIT_PROJECT = 0, JIT_FILTER = 1, JIT_AGGREGATE = 2 };
 bool jit_launch(JitKind kind, const SpecFields &fields, const void *args, int mode, int device, unsigned grid, unsigned block,
                 size_t lds_bytes, hipStream_t stream, hipError_t *err, const char **kernel_name);
 
+// Is the kernel for this shape ready to launch?  In JIT_SYNC mode it is compiled now if need be; otherwise this only
+// looks (and starts nothing).
+bool jit_ready(JitKind kind, const SpecFields &fields, int mode);
+
 // Compiles the kernel for `fields` without touching a device; returns the code object's size.
 // Throws qe::Failure when the compiler rejects the source (the log is the message).
 size_t jit_compile_only(JitKind kind, const SpecFields &fields);

@@ -29,15 +29,22 @@ int64_t filter_num_tiles(int64_t n_rows);
 
 // Hash aggregate update over one batch.
 hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name = nullptr);
-// LDS bytes per slot for a given accumulator count, and the slot count chosen.
-uint32_t aggregate_lds_slots(int n_accs, const DeviceInfo &dev, int64_t group_hint);
+// Slots of the workgroup's LDS table (`wide`: for the 1024-thread launch geometry, see AggArgs::block_threads).
+uint32_t aggregate_lds_slots(const AggArgs &args, const DeviceInfo &dev, int64_t group_hint, bool wide);
+// Whether a kernel that can be launched wide exists for this shape right now.
+bool aggregate_wide_available(const AggArgs &args, const DeviceInfo &dev);
 
 // High-cardinality mode, second phase (see AggSpill): partition the spill log by key hash
 // (count, scan by the caller, move), then aggregate partition by partition.
 size_t spill_cells(int bits, int blocks);
-hipError_t launch_spill_partition(const AggSpill &sp, int n_segments, int bits, int blocks, bool move, int32_t *cells,
-                                  unsigned long long *out_keys, unsigned long long *out_vals, unsigned long long *total,
-                                  hipStream_t stream);
+hipError_t launch_spill_count(const AggSpill &sp, int n_segments, int bits, int blocks, int32_t *cells, unsigned long long *total,
+                              hipStream_t stream);
+int spill_level1_bits(int bits);  // bits of the first scatter pass (== bits: there is only one)
+hipError_t launch_spill_cells_level1(const int32_t *cells, int32_t *cells1, int bits, int blocks, hipStream_t stream);
+hipError_t launch_spill_scatter(const AggSpill &sp, int n_segments, int level, int bits, int bits1, int blocks, const unsigned long long *src_keys,
+                                const unsigned long long *src_vals, uint64_t src_stride, const int32_t *src_cells, int64_t total,
+                                const int32_t *dst_cells, unsigned long long *dst_keys, unsigned long long *dst_vals, uint64_t dst_stride,
+                                hipStream_t stream);
 uint32_t partitioned_lds_slots(int n_accs);
 hipError_t launch_aggregate_partitioned(const PartArgs &args, const DeviceInfo &dev, hipStream_t stream);
 // Workgroups launch_aggregate will use for these arguments (sizes the per-wave spill regions).
@@ -83,8 +90,9 @@ hipError_t launch_count_zero_bits(const uint32_t *bitmap, int64_t n, unsigned lo
 // kernel exists for `args`; otherwise it launches, sets *err and *kernel_name, and returns true.
 bool static_launch_project(const ProjectArgs &args, int grid, hipStream_t stream, hipError_t *err, const char **kernel_name);
 bool static_launch_filter(const FilterArgs &args, int cus, hipStream_t stream, hipError_t *err, const char **kernel_name);
-bool static_launch_aggregate(const AggArgs &args, int grid, size_t lds_bytes, hipStream_t stream, hipError_t *err,
+bool static_launch_aggregate(const AggArgs &args, int grid, int block_threads, size_t lds_bytes, hipStream_t stream, hipError_t *err,
                              const char **kernel_name);
+bool static_has_aggregate(const AggArgs &args);
 int static_kernel_count();
 const char *static_kernel_name(int i);
 

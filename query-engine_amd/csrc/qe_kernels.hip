@@ -147,7 +147,7 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, FULL ? 2 : 3) void qe_aggregate_k
   const uint32_t wave = threadIdx.x >> 6;
   const int64_t n = A.n_rows;
   LdsTable L;
-  agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, A.n_accs);
+  agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, A.n_accs, agg_tracks_validity(A.accs, A.n_accs));
   agg_lds_clear(L, A.accs, A.n_accs);
 
   // wave-uniform descriptors, one per lane (see ProgRegs): task list, key fields, accumulators
@@ -217,143 +217,257 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, FULL ? 2 : 3) void qe_aggregate_k
 }
 
 // ------------------------------------------- high-cardinality second phase
-// The spill log is a set of per-wave segments (segment w: rows [w * rows_per_wave, + counts[w])).
-// Phase 2a counts the rows of every partition per workgroup, 2b scans the counts (partition-major,
-// so the scan IS the layout), 2c moves the rows, 2d aggregates one partition at a time in LDS.
+// The spill log is a set of per-wave segments (segment w: rows [w * rows_per_wave, + counts[w])).  It is partitioned
+// by the top bits of a hash of the key so that one partition's distinct keys fit an LDS table:
+//   count    one pass over the logged keys: rows per (partition, workgroup) cell, for all `bits` at once;
+//   scan     exclusive scan of the cells, partition-major: the scan IS the layout of the partitioned rows;
+//   scatter  the rows move to their partition - in ONE pass when there are at most 64 partitions, else in TWO
+//            (first by the top bits1 bits, then every first-level cell by the remaining bits).  HBM serves
+//            scattered accesses at the rate at which it opens rows, a few G per second whatever their size, so a
+//            partitioning pass is only as fast as its bursts are long: a workgroup collects the rows of a partition
+//            in an LDS stage and writes them out KiB-wise, which 144 KiB of LDS afford for a few dozen partitions
+//            at a time, not for five hundred (one pass over 512 partitions: 64-byte bursts, 0.8 TB/s);
+//   aggregate one partition at a time into a fresh LDS table, flushed into the global table.
+// The count pass serves both scatter levels: workgroup b of the second level takes, for every first-level partition
+// q, exactly the rows workgroup b wrote there in the first level (cell (q, b)), so its rows per final partition are
+// the counts it made itself in the count pass.
 constexpr int PART_THREADS = 1024;
 constexpr int PART_MAX_BITS = 11;
+constexpr int SCATTER_MAX_STAGES = 64;
+constexpr int SCATTER_ROWS = 4;       // rows per thread and round
+constexpr int SCATTER_MAX_INPUTS = 8;  // = SPILL_MAX_INPUTS of the host
 
-__device__ __forceinline__ uint32_t partition_of(unsigned long long key, int bits) { return (uint32_t)(mix64(key) >> (64 - bits)); }
+// Partition of a key: the top bits of the 32-bit hash whose low bits pick the slot in the LDS tables (three 32-bit
+// multiplies; a 64-bit mixer costs several times that, per row and pass).
+__device__ __forceinline__ uint32_t partition_of(unsigned long long key, int bits) { return hash32(key) >> (32 - bits); }
 
-// MOVE = false: histogram only.  MOVE = true: `cursors` holds the scanned start of every
-// (partition, workgroup) cell; rows are copied to their partition.
-template <bool MOVE>
-__global__ __launch_bounds__(PART_THREADS) void qe_spill_partition_kernel(AggSpill sp, int n_segments, int bits, int32_t *cells,
-                                                                            unsigned long long *out_keys, unsigned long long *out_vals,
-                                                                            unsigned long long *total) {
+__global__ __launch_bounds__(PART_THREADS) void qe_spill_count_kernel(AggSpill sp, int n_segments, int bits, int32_t *cells, unsigned long long *total) {
   __shared__ uint32_t s_cell[1 << PART_MAX_BITS];
   const int P = 1 << bits;
-  for (int p = threadIdx.x; p < P; p += blockDim.x) s_cell[p] = MOVE ? (uint32_t)cells[p * gridDim.x + blockIdx.x] : 0u;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) s_cell[p] = 0u;
   __syncthreads();
   unsigned long long mine = 0;
   for (int seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
     const uint32_t cnt = sp.counts[seg];
     const uint64_t base = (uint64_t)seg * sp.rows_per_wave;
-    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-      const unsigned long long key = sp.keys[base + i];
-      const uint32_t p = partition_of(key, bits);
-      const uint32_t pos = atomicAdd(&s_cell[p], 1u);
-      if (MOVE) {
-        out_keys[pos] = key;
-        for (uint32_t v = 0; v < sp.n_inputs; ++v) out_vals[(uint64_t)v * sp.capacity + pos] = sp.vals[(uint64_t)v * sp.capacity + base + i];
-      }
-    }
-    if (!MOVE && threadIdx.x == 0) mine += cnt;
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) atomicAdd(&s_cell[partition_of(sp.keys[base + i], bits)], 1u);
+    if (threadIdx.x == 0) mine += cnt;
   }
-  if (!MOVE) {
-    __syncthreads();
-    for (int p = threadIdx.x; p < P; p += blockDim.x) cells[p * gridDim.x + blockIdx.x] = (int32_t)s_cell[p];
-    if (threadIdx.x == 0 && mine) atomicAdd(total, mine);
-  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < P; p += blockDim.x) cells[p * gridDim.x + blockIdx.x] = (int32_t)s_cell[p];
+  if (threadIdx.x == 0 && mine) atomicAdd(total, mine);
 }
 
-// The move with LDS staging.  Written one row at a time, every store of the plain kernel above opens
-// a different cache line (partitions x workgroups of them are open at once, far more than L2 holds),
-// and the partial lines are written back again and again.  Here a workgroup collects up to S rows per
-// partition in LDS and writes them as one burst, eight lanes to a burst; rows that find their
-// partition's stage full are written directly (rare).  A thread handles up to MOVE_ROWS rows per
-// round with all their loads issued together, and every non-empty stage is flushed each round.
-// Dynamic LDS: keys[P * S], then vals[n_inputs][P * S].
-constexpr int MOVE_MAX_INPUTS = 4;
-constexpr int MOVE_ROWS = 4;
+// First-level cells from the full-depth ones: cells1[q][b] = sum over the `fan` partitions below q of cells[.][b].
+__global__ void qe_spill_cells_level1_kernel(const int32_t *cells, int32_t *cells1, int parts1, int fan, int blocks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= parts1 * blocks) return;
+  const int q = i / blocks, b = i - q * blocks;
+  int32_t sum = 0;
+  for (int f = 0; f < fan; ++f) sum += cells[(q * fan + f) * blocks + b];
+  cells1[i] = sum;
+}
 
-__global__ __launch_bounds__(PART_THREADS) void qe_spill_move_staged_kernel(AggSpill sp, int n_segments, int bits, int S, int rows_per_thread,
-                                                                            const int32_t *cells,
-                                                                            unsigned long long *out_keys, unsigned long long *out_vals) {
+struct ScatterArgs {
+  // level 1 source: the log (sp, n_segments).  Level 2 source: first-level cell (q, this workgroup) of src_keys / src_vals
+  AggSpill sp;
+  int n_segments;
+  int level;                 // 1 or 2
+  const unsigned long long *src_keys;
+  const unsigned long long *src_vals;
+  uint64_t src_stride;       // rows between value columns of the source
+  const int32_t *src_cells;  // level 2: scanned first-level cells [q * blocks + b]
+  int parts1;                // level 2: number of first-level partitions
+  int64_t total;             // level 2: rows in all cells (end of the last one)
+  int bits;                  // hash bits that name a row's partition at this level's depth
+  int stages;                // partitions a workgroup has open at a time (level 1: all of them; level 2: the fan-out)
+  int depth;                 // rows per stage
+  const int32_t *dst_cells;  // scanned cells of this level's depth [p * blocks + b]: where this workgroup's rows of p go
+  unsigned long long *dst_keys;
+  unsigned long long *dst_vals;
+  uint64_t dst_stride;
+  uint32_t n_inputs;
+};
+
+// Workgroup barrier for code whose waves talk through LDS only.  __syncthreads() also waits for every global store the
+// wave has in flight (it is a fence for all memory): after a burst of stores that is the whole trip to HBM, per round.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); vmcnt and expcnt left alone
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// Dynamic LDS: keys[stages * depth], then vals[n_inputs][stages * depth].
+__global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_kernel(const ScatterArgs A) {
   extern __shared__ unsigned long long lds_stage[];
-  __shared__ uint32_t s_cur[1 << PART_MAX_BITS];    // next output row of each partition (this workgroup's cell)
-  __shared__ uint32_t s_cnt[1 << PART_MAX_BITS];    // rows offered to the stage since its last flush
-  __shared__ uint32_t s_ready[1 << PART_MAX_BITS];  // partitions to flush in this round
+  auto BAR = [&]() { lds_barrier(); };
+  __shared__ uint32_t s_cur[SCATTER_MAX_STAGES];    // next output row of each open partition (this workgroup's cell)
+  __shared__ uint32_t s_cnt[SCATTER_MAX_STAGES];    // rows offered to the stage since its last flush
+  __shared__ uint32_t s_ready[SCATTER_MAX_STAGES];  // stages to write out in this round
   __shared__ uint32_t s_nready;
-  const int P = 1 << bits;
+  const int PS = A.stages, S = A.depth;
+  const uint32_t n_in = A.n_inputs;
   unsigned long long *st_keys = lds_stage;
-  unsigned long long *st_vals = lds_stage + (size_t)P * S;
-  const uint32_t n_in = sp.n_inputs;
-  for (int p = threadIdx.x; p < P; p += blockDim.x) {
-    s_cur[p] = (uint32_t)cells[p * gridDim.x + blockIdx.x];
-    s_cnt[p] = 0;
-  }
-  if (threadIdx.x == 0) s_nready = 0;
-  __syncthreads();
+  unsigned long long *st_vals = lds_stage + (size_t)PS * S;
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  const uint32_t stage_mask = (uint32_t)PS - 1u;
 
-  // Burst writes: a group of eight lanes takes one ready partition.
+  // Writes out every stage holding at least `threshold` rows, a wave to a stage: bursts of up to depth x 8 bytes per column.
   auto flush = [&](uint32_t threshold) {
-    for (int p = threadIdx.x; p < P; p += blockDim.x)
-      if (s_cnt[p] >= threshold && s_cnt[p] != 0) s_ready[atomicAdd(&s_nready, 1u)] = (uint32_t)p;
-    __syncthreads();
+    if (threadIdx.x < (uint32_t)PS && s_cnt[threadIdx.x] >= threshold && s_cnt[threadIdx.x] != 0) s_ready[atomicAdd(&s_nready, 1u)] = threadIdx.x;
+    BAR();
     const uint32_t nready = s_nready;
-    const uint32_t sub = threadIdx.x & 7u;
-    for (uint32_t q = threadIdx.x >> 3; q < nready; q += blockDim.x >> 3) {
+    for (uint32_t q = wave; q < nready; q += n_waves) {
       const uint32_t p = s_ready[q];
       const uint32_t offered = s_cnt[p];
       const uint32_t n = offered < (uint32_t)S ? offered : (uint32_t)S;
       const uint32_t base = s_cur[p];
-      for (uint32_t i = sub; i < n; i += 8) out_keys[base + i] = st_keys[(size_t)p * S + i];
+      for (uint32_t i = lane; i < n; i += 64) A.dst_keys[base + i] = st_keys[(size_t)p * S + i];
       for (uint32_t v = 0; v < n_in; ++v)
-        for (uint32_t i = sub; i < n; i += 8) out_vals[(uint64_t)v * sp.capacity + base + i] = st_vals[((size_t)v * P + p) * S + i];
-      if (sub == 0) {  // the group's lanes run in lockstep: everyone has read s_cur / s_cnt above
+        for (uint32_t i = lane; i < n; i += 64) A.dst_vals[(uint64_t)v * A.dst_stride + base + i] = st_vals[((size_t)v * PS + p) * S + i];
+      if (lane == 0) {  // the wave runs in lockstep: every lane has read s_cur / s_cnt above
         s_cur[p] = base + n;
         s_cnt[p] = 0;
       }
     }
-    __syncthreads();
+    BAR();
     if (threadIdx.x == 0) s_nready = 0;
+    BAR();
   };
 
-  // A round = MOVE_ROWS rows per thread of one segment, all their loads in flight together; every
-  // stage that holds anything is written out at the end of the round, so a stage only has to take
-  // one round's rows of its partition (the host picks rows per round and stage depth to match).
-  for (int seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
-    const uint32_t cnt = sp.counts[seg];
-    const uint64_t base = (uint64_t)seg * sp.rows_per_wave;
-    for (uint32_t i0 = 0; i0 < cnt; i0 += blockDim.x * (uint32_t)rows_per_thread) {  // uniform trip count: barriers inside
-      unsigned long long key[MOVE_ROWS], val[MOVE_ROWS][MOVE_MAX_INPUTS];
-      bool have[MOVE_ROWS];
-#pragma unroll
-      for (int r = 0; r < MOVE_ROWS; ++r) {
-        const uint32_t i = i0 + (uint32_t)r * blockDim.x + threadIdx.x;
-        have[r] = r < rows_per_thread && i < cnt;
-        if (have[r]) {
-          key[r] = sp.keys[base + i];
-#pragma unroll
-          for (int v = 0; v < MOVE_MAX_INPUTS; ++v)
-            if ((uint32_t)v < n_in) val[r][v] = sp.vals[(uint64_t)v * sp.capacity + base + i];
-        }
+  // The workgroup's work as a sequence of rounds: SCATTER_ROWS rows per thread out of one segment (level 1: a wave's
+  // log; level 2: one first-level cell).  Everything here is uniform over the workgroup.
+  struct Round {
+    int seg;         // level 1: log segment; level 2: first-level partition
+    uint64_t first;  // first row of the segment in the source
+    uint32_t cnt;    // rows of the segment
+    uint32_t i0;     // first row of the round within the segment
+    bool valid;
+  };
+  const unsigned long long *src_keys = A.level == 1 ? A.sp.keys : A.src_keys;
+  const unsigned long long *src_vals = A.level == 1 ? A.sp.vals : A.src_vals;
+  const uint64_t src_stride = A.level == 1 ? A.sp.capacity : A.src_stride;
+  const int64_t n_cells = (int64_t)A.parts1 * gridDim.x;
+  auto open_segment = [&](Round &r) {  // r.seg names a candidate: skips empty segments, invalid when none is left
+    for (;;) {
+      if (A.level == 1) {
+        if (r.seg >= A.n_segments) break;
+        r.cnt = A.sp.counts[r.seg];
+        r.first = (uint64_t)r.seg * A.sp.rows_per_wave;
+      } else {
+        if (r.seg >= A.parts1) break;
+        const int64_t cell = (int64_t)r.seg * gridDim.x + blockIdx.x;
+        const int64_t first = A.src_cells[cell];
+        const int64_t end = cell + 1 < n_cells ? (int64_t)A.src_cells[cell + 1] : A.total;
+        r.first = (uint64_t)first;
+        r.cnt = (uint32_t)(end - first);
       }
-#pragma unroll
-      for (int r = 0; r < MOVE_ROWS; ++r) {
-        if (have[r]) {
-          const uint32_t p = partition_of(key[r], bits);
-          const uint32_t slot = atomicAdd(&s_cnt[p], 1u);
-          if (slot < (uint32_t)S) {
-            st_keys[(size_t)p * S + slot] = key[r];
-#pragma unroll
-            for (int v = 0; v < MOVE_MAX_INPUTS; ++v)
-              if ((uint32_t)v < n_in) st_vals[((size_t)v * P + p) * S + slot] = val[r][v];
-          } else {
-            const uint32_t pos = atomicAdd(&s_cur[p], 1u);  // stage full: straight to memory
-            out_keys[pos] = key[r];
-#pragma unroll
-            for (int v = 0; v < MOVE_MAX_INPUTS; ++v)
-              if ((uint32_t)v < n_in) out_vals[(uint64_t)v * sp.capacity + pos] = val[r][v];
-          }
-        }
+      if (r.cnt != 0) {
+        r.i0 = 0;
+        r.valid = true;
+        return;
       }
-      __syncthreads();
-      flush(1);
-      __syncthreads();
+      r.seg += A.level == 1 ? (int)gridDim.x : 1;
     }
+    r.valid = false;
+  };
+  auto advance = [&](Round &r) {
+    r.i0 += blockDim.x * (uint32_t)SCATTER_ROWS;
+    if (r.i0 >= r.cnt) {
+      r.seg += A.level == 1 ? (int)gridDim.x : 1;
+      open_segment(r);
+    }
+  };
+  // keys and the first value column of a round's rows: loaded a round ahead, so that the trip to memory overlaps the
+  // staging and the barriers of the round before
+  auto fetch = [&](const Round &r, unsigned long long (&key)[SCATTER_ROWS], unsigned long long (&val0)[SCATTER_ROWS]) {
+#pragma unroll
+    for (int k = 0; k < SCATTER_ROWS; ++k) {
+      const uint32_t i = r.i0 + (uint32_t)k * blockDim.x + threadIdx.x;
+      key[k] = 0;
+      val0[k] = 0;
+      if (r.valid && i < r.cnt) {
+        key[k] = __builtin_nontemporal_load(&src_keys[r.first + i]);
+        if (n_in > 0) val0[k] = __builtin_nontemporal_load(&src_vals[r.first + i]);
+      }
+    }
+  };
+
+  if (threadIdx.x == 0) s_nready = 0;
+  if (threadIdx.x < (uint32_t)PS) {
+    s_cur[threadIdx.x] = A.level == 1 ? (uint32_t)A.dst_cells[threadIdx.x * gridDim.x + blockIdx.x] : 0u;
+    s_cnt[threadIdx.x] = 0;
   }
+  BAR();
+  Round cur;
+  cur.seg = A.level == 1 ? (int)blockIdx.x : 0;
+  cur.first = 0;
+  cur.cnt = 0;
+  cur.i0 = 0;
+  cur.valid = false;
+  open_segment(cur);
+  unsigned long long key[SCATTER_ROWS], val0[SCATTER_ROWS], nkey[SCATTER_ROWS], nval0[SCATTER_ROWS];
+  fetch(cur, key, val0);
+  while (cur.valid) {  // uniform: barriers inside
+    Round nxt = cur;
+    advance(nxt);
+    fetch(nxt, nkey, nval0);
+    if (A.level == 2 && cur.i0 == 0) {
+      // a new first-level cell: its rows go to the partitions below it
+      if (threadIdx.x < (uint32_t)PS) {
+        s_cur[threadIdx.x] = (uint32_t)A.dst_cells[((int64_t)cur.seg * PS + threadIdx.x) * gridDim.x + blockIdx.x];
+        s_cnt[threadIdx.x] = 0;
+      }
+      BAR();
+    }
+    bool have[SCATTER_ROWS];
+    uint32_t slot[SCATTER_ROWS], part[SCATTER_ROWS];
+#pragma unroll
+    for (int k = 0; k < SCATTER_ROWS; ++k) {
+      have[k] = cur.i0 + (uint32_t)k * blockDim.x + threadIdx.x < cur.cnt;
+      part[k] = partition_of(key[k], A.bits) & stage_mask;
+      slot[k] = 0;
+      if (have[k]) {
+        slot[k] = atomicAdd(&s_cnt[part[k]], 1u);
+        if (slot[k] < (uint32_t)S) {
+          st_keys[(size_t)part[k] * S + slot[k]] = key[k];
+          if (n_in > 0) st_vals[(size_t)part[k] * S + slot[k]] = val0[k];
+        } else {
+          slot[k] = 0x80000000u | atomicAdd(&s_cur[part[k]], 1u);  // stage full: straight to memory (rare)
+          A.dst_keys[slot[k] & 0x7fffffffu] = key[k];
+          if (n_in > 0) A.dst_vals[slot[k] & 0x7fffffffu] = val0[k];
+        }
+      }
+    }
+    for (uint32_t v = 1; v < n_in; ++v) {
+      unsigned long long val[SCATTER_ROWS];
+#pragma unroll
+      for (int k = 0; k < SCATTER_ROWS; ++k) {
+        const uint32_t i = cur.i0 + (uint32_t)k * blockDim.x + threadIdx.x;
+        val[k] = have[k] ? src_vals[(uint64_t)v * src_stride + cur.first + i] : 0ull;
+      }
+#pragma unroll
+      for (int k = 0; k < SCATTER_ROWS; ++k) {
+        if (have[k]) {
+          if (slot[k] & 0x80000000u) A.dst_vals[(uint64_t)v * A.dst_stride + (slot[k] & 0x7fffffffu)] = val[k];
+          else st_vals[((size_t)v * PS + part[k]) * S + slot[k]] = val[k];
+        }
+      }
+    }
+    BAR();
+    // half-full stages go out (a round brings a stage a fraction of its depth); everything at the end of a level-2
+    // cell, whose successor's rows go to other partitions
+    const bool cell_ends = A.level == 2 && (!nxt.valid || nxt.seg != cur.seg);
+    flush(cell_ends ? 1u : (uint32_t)S / 2);
+#pragma unroll
+    for (int k = 0; k < SCATTER_ROWS; ++k) {
+      key[k] = nkey[k];
+      val0[k] = nval0[k];
+    }
+    cur = nxt;
+  }
+  flush(1);
 }
 
 // One ticket = one partition: all its rows folded into a fresh LDS table, the table flushed into
@@ -385,18 +499,72 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
     GiveUpWatch watch;
     const int64_t start = A.offsets[p * A.stride];
     const int64_t end = p + 1 < A.n_parts ? (int64_t)A.offsets[(p + 1) * A.stride] : A.total;
-    for (int64_t r0 = start + (int64_t)wave * VM_WAVE_ROWS; r0 < end; r0 += (int64_t)n_waves * VM_WAVE_ROWS) {
-      if (table_given_up(A.table, watch)) break;
-      AggRows G;
-      uint32_t active = 0;
+    // The keys and the first value column of a wave's next 256 rows are loaded while it works on the current ones:
+    // the work is LDS round trips, one after the other, and a memory round trip on top of every step's would double it.
+    const int64_t stride_rows = (int64_t)n_waves * VM_WAVE_ROWS;
+    unsigned long long nkey[VM_R], nval[VM_R];
+    auto fetch = [&](int64_t r0) {
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) {
         const int64_t r = r0 + j * 64 + lane;
-        G.key[j] = 0;
-        G.slot[j] = SLOT_NONE;
+        nkey[j] = 0;
+        nval[j] = 0;
         if (r < end) {
-          G.key[j] = A.keys[r];
-          active |= 1u << j;
+          nkey[j] = __builtin_nontemporal_load(&A.keys[r]);
+          if (A.n_inputs > 0) nval[j] = __builtin_nontemporal_load(&A.vals[r]);
+        }
+      }
+    };
+    int64_t r0 = start + (int64_t)wave * VM_WAVE_ROWS;
+    if (r0 < end) fetch(r0);
+    for (; r0 < end; r0 += stride_rows) {
+      if (table_given_up(A.table, watch)) break;
+      AggRows G;
+      Slot in;
+      in.valid = 0xFu;
+      uint32_t active = 0;
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) {
+        G.key[j] = nkey[j];
+        in.v[j] = nval[j];
+        G.slot[j] = SLOT_NONE;
+        if (r0 + j * 64 + lane < end) active |= 1u << j;
+      }
+      if (r0 + stride_rows < end) fetch(r0 + stride_rows);
+      // The common step: 256 rows, every one of which finds (or claims) a slot in the LDS table - by construction a
+      // partition's keys fit it.  No per-row bookkeeping of who goes where: four lookups, then one LDS operation per
+      // row and accumulator.  Anything else (the partition's last rows, a key the table has no room for) takes the
+      // general path below, which looks the rows up again (a lookup changes nothing but the table's key slots).
+      if (r0 + VM_WAVE_ROWS <= end) {
+        int32_t slot[VM_R];
+        lds_find_or_claim4(L, G.key, 0xFu, LDS_MAX_PROBE, slot);
+        if (__ballot((slot[0] | slot[1] | slot[2] | slot[3]) < 0) == 0) {
+#pragma unroll
+          for (int j = 0; j < VM_R; ++j) atomicAdd(&L.rowcnt[slot[j]], 1u);
+#pragma unroll 1
+          for (int v = 0; v < A.n_inputs; ++v) {
+            if (v > 0) {
+#pragma unroll
+              for (int j = 0; j < VM_R; ++j) in.v[j] = A.vals[(uint64_t)v * A.capacity + r0 + j * 64 + lane];
+            }
+#pragma unroll 1
+            for (int a = 0; a < A.n_accs; ++a) {
+              if (A.acc_col[a] != v) continue;
+              const uint32_t op = A.accs[a].op, in_type = A.accs[a].in_type;
+              unsigned long long *acc = L.acc + (size_t)a * L.stride;
+              if (op == ACC_MIN || op == ACC_MAX) {
+#pragma unroll
+                for (int j = 0; j < VM_R; ++j) {
+                  const bool nan = in_type == VT_F64 && u2d(in.v[j]) != u2d(in.v[j]);  // NaN is ignored by min / max
+                  if (!nan) acc_apply(acc + slot[j], op, ord_image(in.v[j], in_type));
+                }
+              } else {
+#pragma unroll
+                for (int j = 0; j < VM_R; ++j) acc_apply(acc + slot[j], op, op == ACC_COUNT ? 1ull : in.v[j]);
+              }
+            }
+          }
+          continue;
         }
       }
       G.rem = 0;
@@ -405,12 +573,12 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
       agg_lookup<false>(L, A.table, active, lane, G, none);
 #pragma unroll 1
       for (int v = 0; v < A.n_inputs; ++v) {
-        Slot in;
-        in.valid = 0xFu;
+        if (v > 0) {
 #pragma unroll
-        for (int j = 0; j < VM_R; ++j) {
-          const int64_t r = r0 + j * 64 + lane;
-          in.v[j] = r < end ? A.vals[(uint64_t)v * A.capacity + r] : 0ull;
+          for (int j = 0; j < VM_R; ++j) {
+            const int64_t r = r0 + j * 64 + lane;
+            in.v[j] = r < end ? A.vals[(uint64_t)v * A.capacity + r] : 0ull;
+          }
         }
 #pragma unroll 1
         for (int a = 0; a < A.n_accs; ++a)
@@ -841,12 +1009,15 @@ static size_t agg_lds_bytes(int n_accs, uint32_t slots, bool with_nn = true) {
 // 64 KiB table two workgroups fit a compute unit; a low-cardinality aggregate with a 1024-slot table
 // runs four and measures 20-45 % faster), so the caller's group-count hint sizes it: 4 x hint slots,
 // at least 256.  Without a hint the cardinality is unknown and the table takes the full budget.
-uint32_t aggregate_lds_slots(int n_accs, const DeviceInfo &dev, int64_t group_hint) {
-  size_t budget = 64 * 1024;
-  if ((size_t)dev.max_lds < budget) budget = dev.max_lds;
-  uint32_t slots = 4096;
-  static int cap = tuned("QE_AGGREGATE_LDS_SLOTS", 4096);
-  while (slots > 16 && (agg_lds_bytes(n_accs, slots) > budget || slots > (uint32_t)cap)) slots >>= 1;
+// `wide`: the launch is one workgroup of AGG_WIDE_THREADS threads per compute unit, whose table may
+// take nearly all of the unit's LDS.
+uint32_t aggregate_lds_slots(const AggArgs &args, const DeviceInfo &dev, int64_t group_hint, bool wide) {
+  const bool with_nn = agg_tracks_validity(args.accs, args.n_accs);
+  size_t budget = wide ? (size_t)150 * 1024 : (size_t)64 * 1024;  // (wide: the admission tags come on top)
+  if (!wide && (size_t)dev.max_lds < budget) budget = dev.max_lds;
+  uint32_t slots = wide ? 8192 : 4096;
+  static int cap = tuned("QE_AGGREGATE_LDS_SLOTS", 8192);
+  while (slots > 16 && (agg_lds_bytes(args.n_accs, slots, with_nn) > budget || slots > (uint32_t)cap)) slots >>= 1;
   if (group_hint > 0) {
     uint64_t want = 256;
     while (want < (uint64_t)group_hint * 4 && want < slots) want <<= 1;
@@ -855,8 +1026,14 @@ uint32_t aggregate_lds_slots(int n_accs, const DeviceInfo &dev, int64_t group_hi
   return slots;
 }
 
+static bool aggregate_is_wide(const AggArgs &args) { return args.block_threads == (uint32_t)AGG_WIDE_THREADS; }
+
 int aggregate_grid(const AggArgs &args, const DeviceInfo &dev) {
-  size_t lds = agg_lds_bytes(args.n_accs, args.lds_cap);
+  if (aggregate_is_wide(args)) {
+    static int wide_per_cu = tuned("QE_AGGREGATE_WIDE_BLOCKS_PER_CU", 1);
+    return grid_for(args.n_rows, VM_WAVE_ROWS * (AGG_WIDE_THREADS / 64), dev.cus * wide_per_cu);
+  }
+  size_t lds = agg_lds_bytes(args.n_accs, args.lds_cap, agg_tracks_validity(args.accs, args.n_accs));
   // Resident workgroups per compute unit: enough waves to keep about 96 KiB of column loads in
   // flight per compute unit (a wave has 2 KiB per cached column outstanding), within what the LDS
   // tables allow.  Measured optima on MI355X: 3 workgroups for four 8-byte columns, 6 for two;
@@ -875,6 +1052,16 @@ int aggregate_grid(const AggArgs &args, const DeviceInfo &dev) {
   return grid;
 }
 
+// Can this launch use the wide geometry?  Only a kernel specialised for its shape can (the general kernels are built
+// for 256-thread workgroups): one built ahead of time, or one the run-time compiler has ready - or makes ready now,
+// when the context compiles on first use.
+bool aggregate_wide_available(const AggArgs &args, const DeviceInfo &dev) {
+  static int enabled = tuned("QE_AGGREGATE_WIDE", 1);
+  if (enabled == 2 || !dev.specialised) return false;
+  if (static_has_aggregate(args)) return true;
+  return jit_wanted(dev, args.n_rows) && jit_ready(JIT_AGGREGATE, spec_fields(args), dev.jit);
+}
+
 // Dense-key bins (see qe_static.h) for aggregates with few groups whose inputs cannot be null, when
 // the bins fit next to the LDS table without costing a resident workgroup.
 static bool dense_bins_wanted(const AggArgs &args, size_t lds, int grid, const DeviceInfo &dev) {
@@ -890,9 +1077,21 @@ static bool dense_bins_wanted(const AggArgs &args, size_t lds, int grid, const D
 hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name) {
   if (args_in.n_rows <= 0) return hipSuccess;
   AggArgs args = args_in;
-  size_t lds = agg_lds_bytes(args.n_accs, args.lds_cap);
+  size_t lds = agg_lds_bytes(args.n_accs, args.lds_cap, agg_tracks_validity(args.accs, args.n_accs));
   int grid = aggregate_grid(args, dev);
   args.dense_off = 0;
+  if (aggregate_is_wide(args)) {
+    // the caller checked aggregate_wide_available: one of the two specialised routes takes the launch
+    hipError_t werr;
+    static int door = tuned("QE_AGGREGATE_DOOR", 1);
+    if (door != 2 && args.spill.keys != nullptr && lds + 16 + DOOR_ENTRIES * 2 <= (size_t)159 * 1024) {
+      args.door_off = (uint32_t)((lds + 15) & ~(size_t)15);
+      lds = args.door_off + DOOR_ENTRIES * 2;
+    }
+    if (static_launch_aggregate(args, grid, AGG_WIDE_THREADS, lds, stream, &werr, kernel_name)) return werr;
+    if (jit_launch(JIT_AGGREGATE, spec_fields(args), &args, dev.jit, dev.device, grid, AGG_WIDE_THREADS, lds, stream, &werr, kernel_name)) return werr;
+    return hipErrorInvalidConfiguration;
+  }
   if (dev.specialised && dense_bins_wanted(args, lds, grid, dev)) {
     args.dense_off = (int32_t)((lds + 15) & ~(size_t)15);
     lds = (size_t)args.dense_off + dense_bins_bytes(args.n_accs);
@@ -902,7 +1101,7 @@ hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipSt
     if (forced == 0 && grid > dev.cus * 5) grid = dev.cus * 5;
   }
   hipError_t err;
-  if (dev.specialised && static_launch_aggregate(args, grid, lds, stream, &err, kernel_name)) return err;
+  if (dev.specialised && static_launch_aggregate(args, grid, VM_BLOCK_THREADS, lds, stream, &err, kernel_name)) return err;
   if (jit_wanted(dev, args.n_rows) &&
       jit_launch(JIT_AGGREGATE, spec_fields(args), &args, dev.jit, dev.device, grid, VM_BLOCK_THREADS, lds, stream, &err, kernel_name))
     return err;
@@ -915,37 +1114,63 @@ hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipSt
 
 size_t spill_cells(int bits, int blocks) { return ((size_t)1 << bits) * blocks; }
 
-hipError_t launch_spill_partition(const AggSpill &sp, int n_segments, int bits, int blocks, bool move, int32_t *cells,
-                                  unsigned long long *out_keys, unsigned long long *out_vals, unsigned long long *total,
-                                  hipStream_t stream) {
+hipError_t launch_spill_count(const AggSpill &sp, int n_segments, int bits, int blocks, int32_t *cells, unsigned long long *total,
+                              hipStream_t stream) {
   if (bits > PART_MAX_BITS) return hipErrorInvalidValue;
-  if (move) {
-    // stage depth from what 120 KiB of LDS hold; shallow stages are not worth their barriers
-    const size_t row_bytes = 8 * (1 + (size_t)sp.n_inputs);
-    const int P = 1 << bits;
-    int S = (int)((size_t)120 * 1024 / ((size_t)P * row_bytes));
-    if (S > 32) S = 32;
-    // rows per thread and round: a round brings rows_per_thread * 1024 / P rows to a partition on
-    // average; keep that at half the stage depth or less, so that overflowing stages stay rare
-    int rows_per_thread = (int)((int64_t)S * P / (2 * PART_THREADS));
-    if (rows_per_thread > MOVE_ROWS) rows_per_thread = MOVE_ROWS;
-    if (S >= 4 && rows_per_thread >= 1 && sp.n_inputs <= (uint32_t)MOVE_MAX_INPUTS) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)qe_spill_move_staged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-      }
-      hipLaunchKernelGGL(qe_spill_move_staged_kernel, dim3(blocks), dim3(PART_THREADS), (size_t)P * S * row_bytes, stream, sp, n_segments, bits,
-                         S, rows_per_thread, cells, out_keys, out_vals);
-    } else {
-      hipLaunchKernelGGL(qe_spill_partition_kernel<true>, dim3(blocks), dim3(PART_THREADS), 0, stream, sp, n_segments, bits, cells, out_keys,
-                         out_vals, total);
-    }
-  } else {
-    hipLaunchKernelGGL(qe_spill_partition_kernel<false>, dim3(blocks), dim3(PART_THREADS), 0, stream, sp, n_segments, bits, cells, out_keys,
-                       out_vals, total);
+  hipLaunchKernelGGL(qe_spill_count_kernel, dim3(blocks), dim3(PART_THREADS), 0, stream, sp, n_segments, bits, cells, total);
+  return hipGetLastError();
+}
+
+// How the partitioning is split into passes: bits of the first level (the second takes the rest; 0 = one pass).
+int spill_level1_bits(int bits) { return bits <= 6 ? bits : bits - bits / 2; }
+
+hipError_t launch_spill_cells_level1(const int32_t *cells, int32_t *cells1, int bits, int blocks, hipStream_t stream) {
+  const int bits1 = spill_level1_bits(bits);
+  const int parts1 = 1 << bits1, fan = 1 << (bits - bits1);
+  const int n = parts1 * blocks;
+  hipLaunchKernelGGL(qe_spill_cells_level1_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cells, cells1, parts1, fan, blocks);
+  return hipGetLastError();
+}
+
+// One scatter pass.  level 1: the log -> dst by the top `bits` bits (dst_cells = scanned cells of that depth).
+// level 2: first-level cells of src (src_cells scanned, parts1 of them per workgroup) -> dst by `bits` bits, of which
+// the low bits - bits1 select among the partitions below one first-level partition.
+hipError_t launch_spill_scatter(const AggSpill &sp, int n_segments, int level, int bits, int bits1, int blocks, const unsigned long long *src_keys,
+                                const unsigned long long *src_vals, uint64_t src_stride, const int32_t *src_cells, int64_t total,
+                                const int32_t *dst_cells, unsigned long long *dst_keys, unsigned long long *dst_vals, uint64_t dst_stride,
+                                hipStream_t stream) {
+  if (sp.n_inputs > (uint32_t)SCATTER_MAX_INPUTS) return hipErrorInvalidValue;
+  ScatterArgs a{};
+  a.sp = sp;
+  a.n_segments = n_segments;
+  a.level = level;
+  a.src_keys = src_keys;
+  a.src_vals = src_vals;
+  a.src_stride = src_stride;
+  a.src_cells = src_cells;
+  a.parts1 = 1 << bits1;
+  a.total = total;
+  a.bits = bits;
+  a.stages = level == 1 ? 1 << bits : 1 << (bits - bits1);
+  if (a.stages > SCATTER_MAX_STAGES) return hipErrorInvalidValue;
+  const size_t row_bytes = 8 * (1 + (size_t)sp.n_inputs);
+  static int stage_kb = tuned("QE_SCATTER_LDS_KB", 144);
+  size_t depth = (size_t)stage_kb * 1024 / ((size_t)a.stages * row_bytes);
+  if (depth > 1024) depth = 1024;
+  if (depth < 8) return hipErrorInvalidValue;
+  a.depth = (int)depth;
+  a.dst_cells = dst_cells;
+  a.dst_keys = dst_keys;
+  a.dst_vals = dst_vals;
+  a.dst_stride = dst_stride;
+  a.n_inputs = sp.n_inputs;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)qe_spill_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
   }
+  hipLaunchKernelGGL(qe_spill_scatter_kernel, dim3(blocks), dim3(PART_THREADS), (size_t)a.stages * a.depth * row_bytes, stream, a);
   return hipGetLastError();
 }
 

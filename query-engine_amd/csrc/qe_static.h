@@ -499,9 +499,9 @@ __device__ __forceinline__ void dense_fold(const DenseBins &D, const Slot &in, c
 
 // Wave `wave` of the workgroup adds the bins of its share of the keys to the global table.
 template <class Spec>
-__device__ __forceinline__ void dense_flush(const DenseBins &D, const AggTable &T, uint32_t wave, uint32_t lane) {
+__device__ __forceinline__ void dense_flush(const DenseBins &D, const AggTable &T, uint32_t wave, uint32_t n_waves, uint32_t lane) {
   if (!D.on) return;
-  for (uint32_t key = wave; key < DENSE_KEYS; key += VM_BLOCK_WAVES) {
+  for (uint32_t key = wave; key < DENSE_KEYS; key += n_waves) {
     const unsigned long long rows = wave_sum_u64(D.rows[key * 64u + lane]);
     if (rows == 0) continue;
     long long g = -1;
@@ -558,7 +558,8 @@ __device__ __forceinline__ void agg_tasks_static(const AggArgs &A, const LdsTabl
       // (with the wave-wide reduction of a key that dominates what is left: skewed keys beyond the two hot ones
       // would otherwise meet on one LDS address row by row - zipf s = 2 over 100 keys 2.1 ms per 64 M rows, with it
       // 0.9 ms; the narrow-row kernels, whose body exists twice, have no registers to spare for it: 0.50 -> 0.72 ms)
-      agg_lookup<(spec_row_bytes<Spec>() >= 16)>(L, A.table, rest, lane, G, sp);
+      if (__ballot(rest != 0) != 0)  // (else the bins and the hot keys took every row: the common step of a low-cardinality aggregate)
+        agg_lookup<(spec_row_bytes<Spec>() >= 16), (spec_row_bytes<Spec>() < 16)>(L, A.table, rest, lane, G, sp);
     } else {
       if (__ballot((hm[0] | hm[1]) != 0) != 0) hot_fold<Spec, (int)idx>(C, S[0], hm);
       if (dm != 0) dense_fold<Spec, (int)idx>(D, S[0], G.key, dm, lane);
@@ -570,18 +571,39 @@ __device__ __forceinline__ void agg_tasks_static(const AggArgs &A, const LdsTabl
   }
 }
 
+// Does any accumulator of the shape keep a count of its valid inputs?  (Only then does the LDS table carry them.)
 template <class Spec>
-__global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_aggregate_static(const AggArgs A) {
+constexpr bool spec_tracks_validity() {
+  for (int a = 0; a < Spec::n_accs; ++a)
+    if (Spec::acc_track[a] != 0) return true;
+  return false;
+}
+
+// Launched with 256 threads per workgroup, several workgroups to a compute unit - or, when rows are expected to miss
+// the LDS table in numbers (high-cardinality mode), with one workgroup of 1024 threads per compute unit, whose sixteen
+// waves share one table four times the size: the same waves in flight, a quarter fewer rows that miss.  Either way a
+// lane has 128 registers.
+// Narrow rows with few accumulators stream fastest with five waves per SIMD (96 registers a lane); the others take the 128
+// that four waves - a 1024-thread workgroup - leave.
+template <class Spec>
+constexpr int spec_min_waves_per_simd() {
+  return spec_row_bytes<Spec>() <= 16 && Spec::n_accs <= 2 ? 5 : 4;
+}
+
+template <class Spec>
+__global__ __launch_bounds__(AGG_WIDE_THREADS, spec_min_waves_per_simd<Spec>()) void qe_aggregate_static(const AggArgs A) {
   extern __shared__ unsigned long long lds_raw[];
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t n_waves = blockDim.x >> 6;
   const int64_t n = A.n_rows;
   LdsTable L;
-  agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, Spec::n_accs);
+  agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, Spec::n_accs, spec_tracks_validity<Spec>());
   DenseBins D;
   D.on = A.dense_off != 0;
   D.rows = (uint32_t *)((char *)lds_raw + A.dense_off);
   D.acc = (unsigned long long *)(D.rows + DENSE_KEYS * 64u);
+  if (A.door_off != 0) L.door = (uint16_t *)((char *)lds_raw + A.door_off);
   dense_clear<Spec>(D);
   agg_lds_clear(L, A.accs, Spec::n_accs);  // ends with a barrier
 
@@ -625,22 +647,22 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_aggregate_static(const
   GiveUpWatch steps_done;
   steps_done.on = A.spill.keys == nullptr;
   if constexpr (spec_row_bytes<Spec>() < 16) {
-    const int64_t ws0 = (int64_t)blockIdx.x * VM_BLOCK_WAVES + __builtin_amdgcn_readfirstlane(wave);
-    for (int64_t ws = ws0; ws < nsteps; ws += (int64_t)gridDim.x * VM_BLOCK_WAVES) {
+    const int64_t ws0 = (int64_t)blockIdx.x * n_waves + __builtin_amdgcn_readfirstlane(wave);
+    for (int64_t ws = ws0; ws < nsteps; ws += (int64_t)gridDim.x * n_waves) {
       if (table_given_up(A.table, steps_done)) nsteps = 0;  // (a shrinking bound, not a second exit: the loop keeps its shape)
       const int64_t row0 = ws * VM_WAVE_ROWS;
       if (row0 + VM_WAVE_ROWS <= n) step(row0, 0xFu);
       else step(row0, in_range_bits(row0, lane, n));
     }
   } else {
-    for (int64_t ws = (int64_t)blockIdx.x * VM_BLOCK_WAVES + wave; ws < nsteps; ws += (int64_t)gridDim.x * VM_BLOCK_WAVES) {
+    for (int64_t ws = (int64_t)blockIdx.x * n_waves + wave; ws < nsteps; ws += (int64_t)gridDim.x * n_waves) {
       if (table_given_up(A.table, steps_done)) nsteps = 0;
       step(ws * VM_WAVE_ROWS, in_range_bits(ws * VM_WAVE_ROWS, lane, n));
     }
   }
   spill_end(A.spill, sp, wave, lane);
   __syncthreads();  // every wave's bin updates are in
-  dense_flush<Spec>(D, A.table, wave, lane);
+  dense_flush<Spec>(D, A.table, wave, n_waves, lane);
   hot_flush<Spec, 0>(C, A.table, lane, (C.valid & 1u) != 0);
   hot_flush<Spec, 1>(C, A.table, lane, (C.valid & 2u) != 0);
   agg_flush(L, A.table, A.accs, Spec::n_accs);

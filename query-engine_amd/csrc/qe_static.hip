@@ -18,7 +18,7 @@ struct Entry {
   int n_sig;
   void (*project)(const ProjectArgs &, int, hipStream_t);
   void (*filter)(const FilterArgs &, int, hipStream_t);
-  void (*aggregate)(const AggArgs &, int, size_t, hipStream_t);
+  void (*aggregate)(const AggArgs &, int, int, size_t, hipStream_t);
 };
 
 template <class Spec>
@@ -36,8 +36,16 @@ void run_filter(const FilterArgs &a, int cus, hipStream_t s) {
   hipLaunchKernelGGL(qe_filter_static<Spec>, dim3((unsigned)grid), dim3(G::WAVES * 64), 0, s, b);
 }
 template <class Spec>
-void run_aggregate(const AggArgs &a, int grid, size_t lds, hipStream_t s) {
-  hipLaunchKernelGGL(qe_aggregate_static<Spec>, dim3(grid), dim3(VM_BLOCK_THREADS), lds, s, a);
+void run_aggregate(const AggArgs &a, int grid, int block_threads, size_t lds, hipStream_t s) {
+  if (lds > 64 * 1024) {
+    static bool raised = false;  // per kernel: this function exists once per Spec
+    if (!raised) {
+      (void)hipFuncSetAttribute((const void *)qe_aggregate_static<Spec>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipGetLastError();  // a runtime that takes no such attribute simply allows what the device has
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(qe_aggregate_static<Spec>, dim3(grid), dim3(block_threads), lds, s, a);
 }
 
 #define QE_ENTRY_PROJECT(S) Entry{S::name, S::sig, S::n_sig, run_project<S>, nullptr, nullptr},
@@ -74,11 +82,16 @@ bool static_launch_filter(const FilterArgs &args, int cus, hipStream_t stream, h
   return true;
 }
 
-bool static_launch_aggregate(const AggArgs &args, int grid, size_t lds_bytes, hipStream_t stream, hipError_t *err,
+bool static_has_aggregate(const AggArgs &args) {
+  const Entry *e = find(signature(args));
+  return e && e->aggregate;
+}
+
+bool static_launch_aggregate(const AggArgs &args, int grid, int block_threads, size_t lds_bytes, hipStream_t stream, hipError_t *err,
                              const char **kernel_name) {
   const Entry *e = find(signature(args));
   if (!e || !e->aggregate) return false;
-  e->aggregate(args, grid, lds_bytes, stream);
+  e->aggregate(args, grid, block_threads, lds_bytes, stream);
   *err = hipGetLastError();
   if (kernel_name) *kernel_name = e->name;
   return true;

@@ -23,6 +23,7 @@ constexpr int VM_MAX_DEPTH = 4;
 constexpr int VM_MAX_OUTS = 12;
 constexpr int VM_MAX_KEYS = 4;
 constexpr int VM_MAX_ACCS = 16;
+constexpr int AGG_WIDE_THREADS = 1024;  // the specialised aggregate kernels' wide launch: one workgroup of 16 waves per compute unit
 constexpr int VM_NCACHE = 6;          // columns whose loads are issued together at the start of a wave-step
 
 // Filter tiles: 4 steps of 1024 rows = 4096 rows per ticket.
@@ -223,7 +224,16 @@ struct AggArgs {
   uint32_t lds_limit;  // stop claiming LDS slots past this many
   AggSpill spill;
   uint8_t spill_col[VM_MAX_ACCS];  // value column an accumulator's input is logged to; 0xff: not this one
+  uint32_t block_threads;          // host only: threads per workgroup of the launch (0 = VM_BLOCK_THREADS)
+  uint32_t door_off;               // byte offset of the admission tags in dynamic LDS (high-cardinality mode); 0 = none
 };
+
+// Does the workgroup's LDS table keep per-accumulator counts of valid inputs?  Host and device size the table alike.
+inline __host__ __device__ bool agg_tracks_validity(const VmAcc *accs, int n_accs) {
+  for (int a = 0; a < n_accs; ++a)
+    if (accs[a].track_nn) return true;
+  return false;
+}
 
 // Second phase of the high-cardinality mode: the spilled rows, partitioned by key hash.
 struct PartArgs {
