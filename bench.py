@@ -67,6 +67,21 @@ def batch_as_block(torch, batch, n_cols):
     return torch.as_tensor(DevArray(base, words, "<i8"), device="cuda"), [o // 8 for o in offs], rows
 
 
+class StdoutToStderr:
+    """Whatever native libraries write to file descriptor 1 meanwhile goes to stderr (RCCL prints a version banner on stdout
+    when its first communicator comes up): stdout carries the one JSON line and nothing else."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def load_launcher():
     """query-engine_amd/launcher.py by path: importing the package would load the HIP library, and the ranks must be
     started before this process has anything to do with a GPU."""
@@ -111,10 +126,12 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+        with StdoutToStderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()  # brings torch's communicator up here, inside the redirection
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
@@ -175,13 +192,29 @@ def main():
     default_flags = qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP
     if deferred:
         ctx.set_flags(default_flags | qe.FLAG_DEFERRED_GROUP_COUNT)
+    comm, comm_note = None, None
     if multi:
         from importlib import import_module
         D = import_module("query-engine_amd.distributed")
         layout = [torch.int64, torch.float64, torch.int64]
-        if partitioned:
+        # The exchange itself runs inside the library (qe_comm_init / qe_exchange_*: its own RCCL communicator, device-side
+        # scatter, grouped collectives, no host synchronisation); torch.distributed only carries the rendezvous id, the
+        # barrier and the max over ranks.  QE_BENCH_EXCHANGE=torch keeps the exchange in torch.distributed (and is what a
+        # gloo rehearsal uses); a library communicator that cannot be set up is reported and the torch path takes over.
+        if backend == "nccl" and os.environ.get("QE_BENCH_EXCHANGE", "abi") == "abi":
+            try:
+                with StdoutToStderr():
+                    comm = D.make_comm(qe, ctx, dist, rank, world)
+            except qe.QeError as e:
+                comm_note = f"qe_comm_init failed ({e}); exchange through torch.distributed"
+            ok = torch.tensor([1 if comm else 0], dtype=torch.int64, device=xdev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not int(ok.item()) and comm:
+                comm.close()
+                comm, comm_note = None, "qe_comm_init failed on another rank; exchange through torch.distributed"
+        if partitioned and not comm:
             xch = D.KeyPartitionedExchange(torch, dist, xdev, world, layout)
-        else:
+        elif not comm:
             first = list(local_plan().execute())[0]
             max_g = first.num_rows  # rows of a partial table = slots of its group table
             xch = D.PartialExchange(torch, dist, xdev, world, max_g, layout)
@@ -194,7 +227,7 @@ def main():
     # the collective's latency and the small kernels of the merge.  With one rank over RCCL it measured 3 % slower than
     # one stream (event and stream hand-over costs, nothing to hide); whether a real 8-GPU all-gather's latency
     # turns that around can only be measured on such a node.
-    two_streams = multi and deferred and backend == "nccl" and os.environ.get("QE_BENCH_SIDE_STREAM", "0") == "1"
+    two_streams = multi and deferred and backend == "nccl" and not comm and os.environ.get("QE_BENCH_SIDE_STREAM", "0") == "1"
     if two_streams:
         from collections import deque
         side_stream = torch.cuda.Stream(device=dev)
@@ -212,6 +245,16 @@ def main():
 
     def merge(part):
         """Exchange of this rank's partial table and the FINAL aggregate over what arrives."""
+        if comm:
+            # rows nobody filled are zero: COUNT(*) > 0 under the FINAL aggregate keeps the real ones
+            if partitioned:
+                got = comm.exchange_by_key(part, 1, args.groups)  # a rank's table has at most one row per key of the domain
+                cap = max(64, 2 * args.groups // world)
+            else:
+                got = comm.all_gather(part, part.num_rows)  # deferred mode: one row per table slot, the same number on every rank
+                cap = hint
+            real = qe.SelectionExec([qe.ScanExec(ctx, [got])], qe.GtExpression(C(2), qe.LiteralInt64Expression(0)))
+            return list(qe.final_plan(real, 1, aggs(1), group_capacity_hint=cap).execute())[0]
         cols = [column_as_tensor(torch, part.column_desc(i), qe) for i in range(3)]
         # the only collective of the plan: the exchange of the partial tables over xGMI
         if partitioned:
@@ -291,6 +334,7 @@ def main():
                                       "pci_bus_id": getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None)})
         topology = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                     "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
+                    "library_rccl_version": comm.rccl_version if comm else None,
                     "launched_by": "bench.py (child processes)" if os.environ.get("QE_BENCH_SPAWNED") else "external launcher" if launched else "none",
                     "ranks": here}
     if world != args.gpus:
@@ -327,8 +371,11 @@ def main():
                    "host_sync": "none inside a step (deferred group count); barrier + device synchronise around the timed steps" if deferred
                    else "per aggregate",
                    "streams": "PARTIAL aggregate on one stream, exchange + FINAL merge on a second" if two_streams else "one",
-                   "merge": (f"{'rccl' if backend == 'nccl' else backend} " + ("all_to_all by key owner" if partitioned else "all_gather") +
-                             " + FINAL aggregate") if multi else "none"},
+                   "merge": ((("rccl inside the library (qe_exchange_by_key: owner hash + scatter kernel, grouped send / recv)" if partitioned else
+                               "rccl inside the library (qe_exchange_all_gather)") if comm else
+                              (f"{'rccl' if backend == 'nccl' else backend} through torch.distributed, " +
+                               ("all_to_all by key owner" if partitioned else "all_gather"))) + " + FINAL aggregate") if multi else "none",
+                   "merge_note": comm_note},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kname,
                      "avg_launch_ms": avg_ms, "rows_per_launch": rows_per_launch},
@@ -359,6 +406,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.cpu_rows, seed)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if comm:
+        comm.close()
     if multi:
         dist.destroy_process_group()
 

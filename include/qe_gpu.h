@@ -307,6 +307,46 @@ qe_status qe_plan_execute(qe_plan *plan, qe_iter **out);
 qe_status qe_iter_next(qe_iter *iter, qe_batch **out);
 void qe_iter_free(qe_iter *iter);
 
+/* ------------------------------------------------ multi-GPU exchange (RCCL) */
+/* No counterpart in the reference (a single-threaded pull iterator,
+ * physical_plan/mod.rs:58).  One process per GPU: every rank runs the plan over
+ * its row range with QE_AGG_MODE_PARTIAL, the partial tables meet in ONE
+ * exchange, a QE_AGG_MODE_FINAL aggregate merges what arrives - the merge the
+ * reference performs batch by batch (physical_plan/mod.rs:298-374), across
+ * devices.  RCCL (librccl.so) is bound when the first of these calls is made;
+ * a process that never calls them does not need it. */
+typedef struct qe_comm qe_comm;
+#define QE_COMM_ID_BYTES 128
+/* The communicator's rendezvous id (ncclGetUniqueId): made by ONE rank and
+ * handed to every rank by the host program's own means (a file, a socket, MPI,
+ * torch.distributed ...). */
+qe_status qe_comm_unique_id(uint8_t *id /* [QE_COMM_ID_BYTES] */);
+/* Collective over all `world` ranks (ncclCommInitRank) on the context's device
+ * and stream; every exchange of this communicator is queued on that stream. */
+qe_status qe_comm_init(qe_context *ctx, int32_t rank, int32_t world, const uint8_t *id, qe_comm **out);
+/* Any of the outputs may be NULL.  rccl_version as ncclGetVersion reports it. */
+qe_status qe_comm_info(const qe_comm *comm, int32_t *rank, int32_t *world, int32_t *rccl_version);
+void qe_comm_free(qe_comm *comm);
+/* Few groups: every rank receives every rank's partial table.  `partial`: the
+ * device-resident output of a PARTIAL aggregate (Int32 / Int64 / Float64
+ * columns).  `padded_rows` (the same on every rank, at least every rank's row
+ * count; a multiple of 32 when a column can be null): the output has
+ * world x padded_rows rows, rank r's table at rows [r * padded_rows, ...), rows
+ * nobody filled all zero - a COUNT(*) column tells them apart (count > 0), so a
+ * Selection on it under the FINAL aggregate merges everything in one launch.
+ * One grouped ncclAllGather; nothing is read back to the host, nothing waits. */
+qe_status qe_exchange_all_gather(qe_comm *comm, const qe_batch *partial, int64_t padded_rows, qe_batch **out);
+/* Many groups: every partial row goes to the rank that owns its key (hash of the
+ * first `n_key_columns` columns modulo the ranks), so that each rank merges
+ * only its share of the groups and the result is the concatenation over the
+ * ranks.  Device-side owner hash and scatter into per-peer blocks of a fixed
+ * size (derived from `max_rows_per_rank`, a bound on any rank's row count, the
+ * same on every rank), then grouped ncclSend / ncclRecv: W - 1 direct transfers
+ * per rank at once.  The output has world x block rows, unfilled ones all zero
+ * (as above).  Nothing waits for the device: a block that overflows is reported
+ * by the next qe_context_synchronize (QE_ERR_AGG_CAPACITY). */
+qe_status qe_exchange_by_key(qe_comm *comm, const qe_batch *partial, int32_t n_key_columns, int64_t max_rows_per_rank, qe_batch **out);
+
 /* -------------------------------------------- selection without allocation */
 /* No counterpart in the reference.  For callers that cannot allocate device
  * memory while they run - code under HIP graph capture, tight serving loops,

@@ -108,6 +108,12 @@ ABI = {
     "qe_plan_execute": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "qe_iter_next": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "qe_iter_free": (None, [C.c_void_p]),
+    "qe_comm_unique_id": (C.c_int32, [C.c_char_p]),
+    "qe_comm_init": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "qe_comm_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "qe_comm_free": (None, [C.c_void_p]),
+    "qe_exchange_all_gather": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "qe_exchange_by_key": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
     "qe_selection_noalloc": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(qe_column),
                                          C.POINTER(C.c_int64)]),
     "qe_generate_column": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_double, C.c_double,
@@ -426,6 +432,56 @@ class Batch:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """The exchange step of a multi-GPU aggregate over RCCL (qe_comm_*, qe_exchange_*): one per rank, on the context's
+    device and stream.  `Comm.unique_id()` on one rank, the bytes handed to every rank by the caller's own means."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(lib.qe_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx, rank, world, unique_id):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique id must be COMM_ID_BYTES long")
+        h = C.c_void_p()
+        _check(lib.qe_comm_init(ctx._h, rank, world, unique_id, C.byref(h)))
+        self._h, self.ctx, self.rank, self.world = h, ctx, rank, world
+
+    @property
+    def rccl_version(self):
+        v = C.c_int32()
+        _check(lib.qe_comm_info(self._h, None, None, C.byref(v)))
+        return v.value
+
+    def all_gather(self, partial, padded_rows):
+        """Every rank's partial table in one batch of world x padded_rows rows (unfilled rows zero)."""
+        h = C.c_void_p()
+        _check(lib.qe_exchange_all_gather(self._h, partial._h, padded_rows, C.byref(h)))
+        return Batch(self.ctx, h)
+
+    def exchange_by_key(self, partial, n_key_columns, max_rows_per_rank):
+        """The rows whose key this rank owns, from all ranks, in one batch (unfilled rows zero)."""
+        h = C.c_void_p()
+        _check(lib.qe_exchange_by_key(self._h, partial._h, n_key_columns, max_rows_per_rank, C.byref(h)))
+        return Batch(self.ctx, h)
+
+    def close(self):
+        if self._h:
+            lib.qe_comm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -170,7 +170,8 @@ void Context::check_deferred() {
   QE_HIP(hipMemcpyAsync(host_counters + 40, counters + 40, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
   sync();
   if (host_counters[40])
-    fail(QE_ERR_AGG_CAPACITY, "a deferred aggregate overflowed its group table: give a larger group_capacity_hint or clear QE_FLAG_DEFERRED_GROUP_COUNT");
+    fail(QE_ERR_AGG_CAPACITY, "a deferred aggregate overflowed its group table (give a larger group_capacity_hint or clear QE_FLAG_DEFERRED_GROUP_COUNT), "
+                               "or an exchange by key one of its peer blocks (give a larger max_rows_per_rank)");
 }
 
 size_t bitmap_bytes(int64_t n) { return (size_t)((n + 255) / 256) * 32 + 32; }

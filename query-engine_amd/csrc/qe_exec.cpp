@@ -1680,6 +1680,8 @@ const qe::Batch &qe_batch_ref(const qe_batch *batch) {
   return batch->b;
 }
 qe::Context *qe_context_ref(qe_context *ctx) { return &ctx->c; }
+std::shared_ptr<qe::Context> qe_context_share(qe_context *ctx) { return ctx->sp; }
+qe_batch *qe_batch_wrap(const qe::Batch &b) { return new qe_batch{b}; }
 qe_plan *qe_plan_wrap(std::unique_ptr<qe::Plan> plan) { return new qe_plan{std::move(plan)}; }
 
 extern "C" {

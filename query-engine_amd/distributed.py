@@ -151,3 +151,21 @@ class KeyPartitionedExchange:
         self.dist.all_to_all_single(out, payload, output_split_sizes=recv, input_split_sizes=send)
         return [out[:, i].contiguous().view(torch.float64) if d == torch.float64 else out[:, i].contiguous()
                 for i, d in enumerate(self.dtypes)]
+
+
+def make_comm(qe, ctx, dist, rank, world):
+    """A qe.Comm (the library's own RCCL communicator: qe_comm_init) for this rank.  The 128-byte rendezvous id is made
+    by rank 0 and handed to the others through torch.distributed, whatever its backend: the exchanges themselves
+    (qe_exchange_all_gather / qe_exchange_by_key) never touch torch.  Raises qe.QeError on every rank when rank 0
+    could not make an id (no RCCL to load), so that no rank is left waiting in the rendezvous."""
+    ids, failure = [None], None
+    if rank == 0:
+        try:
+            ids[0] = qe.Comm.unique_id()
+        except qe.QeError as e:
+            failure = e
+    if world > 1:
+        dist.broadcast_object_list(ids, src=0)
+    if ids[0] is None:
+        raise failure if failure is not None else qe.QeError(41)
+    return qe.Comm(ctx, rank, world, ids[0])
