@@ -593,6 +593,16 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
           {"groups": out.num_rows, "note": "not HBM bound: see kernels_ms_per_step"}, steps=2)
     del zk, b4, out
 
+    # The one workload the reference's own tests pin: test_filter (tests/mod.rs:138-188) - Scan -> Selection(gender ==
+    # "Female"), all 13 columns of userdata.parquet kept (10 of them Utf8) - at 100 M rows: the fixture's 1000 rows
+    # repeated, in batches of 10 M rows (Utf8Array<i32> offsets bound a batch's bytes per column to 2 GiB).
+    ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_JIT_SYNC)  # the predicate's kernel is compiled during the warm-up step
+    try:
+        res["utf8_test_filter_shape_100M"] = utf8_filter_config(qe, ctx, torch, dev)
+    except FileNotFoundError as e:
+        res["utf8_test_filter_shape_100M"] = {"skipped": str(e)}
+    ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP)
+
     # The headline plan read straight off a Parquet file (uncompressed, PLAIN Float64 + dictionary Int64 key; 16 M
     # rows in row groups of 8 M): host reads the page cache into pinned memory, the GPU decodes.  Host-link bound.
     try:
@@ -600,6 +610,66 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
     except ImportError as e:  # pyarrow writes the file
         res["parquet_scan_headline_plan_16M"] = {"skipped": str(e)}
     return res
+
+
+USERDATA_COLUMNS = ["registration_dttm", "id", "first_name", "last_name", "email", "gender", "ip_address", "cc", "country", "birthdate",
+                    "salary", "title", "comments"]
+
+
+def utf8_filter_config(qe, ctx, torch, dev, repeats=10_000, n_batches=10):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "userdata.npz"), allow_pickle=False)
+    base_rows = 1000
+    rows = base_rows * repeats
+    cols, keep, in_bytes = [], [], 0
+    for name in USERDATA_COLUMNS:
+        valid = z[name + ".valid"]
+        d = {"length": rows}
+        if not valid.all():
+            bits = torch.from_numpy(np.packbits(valid, bitorder="little")).to(dev).repeat(repeats)  # 1000 rows = 125 whole bytes
+            pad = torch.zeros(64, dtype=torch.uint8, device=dev)
+            bits = torch.cat([bits, pad])
+            keep.append(bits)
+            d["validity"], d["null_count"] = bits.data_ptr(), int((~valid).sum()) * repeats
+            in_bytes += rows // 8
+        if name + ".offsets" in z:
+            offs, data = z[name + ".offsets"].astype(np.int64), z[name + ".bytes"]
+            total = int(offs[-1])
+            o = (torch.from_numpy(offs[:-1]).to(dev)[None, :] + total * torch.arange(repeats, device=dev, dtype=torch.int64)[:, None]).reshape(-1)
+            o = torch.cat([o, torch.tensor([total * repeats], device=dev, dtype=torch.int64)]).to(torch.int32)
+            b = torch.cat([torch.from_numpy(data[:total].copy()).to(dev).repeat(repeats), torch.zeros(64, dtype=torch.uint8, device=dev)])
+            keep += [o, b]
+            d.update(type=qe.TYPE_UTF8, offsets=o.data_ptr(), values=b.data_ptr(), values_bytes=total * repeats)
+            in_bytes += 4 * (rows + 1) + total * repeats
+        else:
+            v = z[name + ".values"]
+            t = torch.from_numpy(v).to(dev).repeat(repeats)
+            keep.append(t)
+            ty = qe.TYPE_TIMESTAMP_NS if name == "registration_dttm" else {np.dtype(np.int32): qe.TYPE_INT32, np.dtype(np.int64): qe.TYPE_INT64,
+                                                                            np.dtype(np.float64): qe.TYPE_FLOAT64}[v.dtype]
+            d.update(type=ty, values=t.data_ptr())
+            in_bytes += v.dtype.itemsize * rows
+        cols.append(d)
+    torch.cuda.synchronize()
+    batches = [qe.Batch.from_device_columns(ctx, cols, keepalive=keep) for _ in range(n_batches)]  # the same buffers, scanned n_batches times
+    gender = USERDATA_COLUMNS.index("gender")
+
+    def plan():
+        sel = qe.SelectionExec([qe.ScanExec(ctx, batches)], qe.EqExpression(qe.ColumnExpression(gender), qe.LiteralStringExpression("Female")))
+        n_out, out_bytes = 0, 0
+        for out in sel.execute():  # one output batch per input batch, dropped as the next one comes
+            n_out += out.num_rows
+            for i in range(out.num_columns):
+                dsc = out.column_desc(i)
+                out_bytes += dsc.values_bytes + (4 * (dsc.length + 1) if dsc.offsets else 0) + (dsc.length // 8 if dsc.validity else 0)
+        return n_out, out_bytes
+    dt, prof, (n_out, out_bytes) = timed(ctx, torch, plan, 2, 1)
+    total_rows = rows * n_batches
+    moved = in_bytes * n_batches + out_bytes
+    return {"rows": total_rows, "rows_out": n_out, "columns": 13, "utf8_columns": 10, "rows_per_s": total_rows / dt, "ms_per_step": dt * 1e3,
+            "bytes_per_row": moved / total_rows, "end_to_end_GBps": moved / dt / 1e9, "frac_hbm_peak_end_to_end": moved / dt / 1e9 / HBM_PEAK_GBS,
+            "kernels_ms_per_step": {kk: vv["ms"] / 2 for kk, vv in prof.items()},
+            "note": "algorithmic bytes = every input buffer (values, offsets, validity) read once + every output buffer written once; "
+                    "the predicate runs in a kernel compiled for the shape at run time when the context allows (QE_JIT), else in the general kernel"}
 
 
 def parquet_config(qe, ctx, torch, k, a, b, c, rows):

@@ -579,7 +579,7 @@ ExprCost expr_cost(const ExprPtr &e, const Schema &schema) {
     return c;
   }
   if (expr_type(e->l, schema) == QE_TYPE_UTF8) {  // one comparison instruction; a literal operand is (address, length)
-    c.insns = 1, c.lits = 2, c.slots = 1;
+    c.insns = 1, c.lits = 3, c.slots = 1;
     return c;
   }
   const ExprCost a = expr_cost(e->l, schema), b = expr_cost(e->r, schema);
@@ -760,6 +760,19 @@ void Compiler::emit(const ExprPtr &e, int depth) {
     if (col->kind != EK_COLUMN || litv->kind != EK_LITERAL)
       fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression `" + expr_to_string(e) + "` is not supported.");
     if (!litv->valid) fail(QE_ERR_SCALAR_TO_ARRAY, "Couldn't convert Scalar value `null` to array.");
+    if (litv->sval.size() <= 16) {
+      // a short literal travels in the program's literals (two words of bytes and the length): no device copy, and
+      // the comparison is one the shape-specialised kernels implement
+      if (n_lits + 3 > VM_MAX_LITS) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many literals for one kernel.");
+      uint64_t w[2] = {0, 0};
+      for (size_t i = 0; i < litv->sval.size(); ++i) w[i >> 3] |= (uint64_t)(unsigned char)litv->sval[i] << (8 * (i & 7));
+      const int li = n_lits;
+      prog.lits[n_lits++] = w[0];
+      prog.lits[n_lits++] = w[1];
+      prog.lits[n_lits++] = (uint64_t)litv->sval.size();
+      push_insn(ne ? OP_UTF8_NE_LIT16 : OP_UTF8_EQ_LIT16, depth, (uint32_t)col_slot(col->index) | ((uint32_t)li << 8));
+      return;
+    }
     if (!ctx) fail(QE_ERR_INVALID_ARGUMENT, "a utf8 literal needs a device context");
     BufferPtr buf = device_buffer(ctx, litv->sval.size() + 1);
     QE_HIP(hipMemcpyAsync(buf->ptr, litv->sval.data(), litv->sval.size(), hipMemcpyHostToDevice, ctx->stream));

@@ -131,6 +131,39 @@ __device__ __forceinline__ bool utf8_equal(const uint8_t *a, const uint8_t *b, i
   return true;
 }
 
+// Rows of the lane (bit j of the result) whose string in `col` equals a literal of `len` <= 16 bytes held in two
+// registers (`lo`: bytes 0..7, `hi`: bytes 8..15).  The length decides most rows; the others read their bytes once,
+// nothing else (a literal in memory costs a second load per byte compared).
+__device__ __forceinline__ uint32_t utf8_equals_lit16(const int32_t *offsets, const uint8_t *bytes, uint64_t lo, uint64_t hi, uint32_t len,
+                                                    int64_t row0, uint32_t lane, uint32_t active) {
+  uint32_t eq = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if ((active >> (2 * h)) & 3u) {
+      const int64_t r = row0 + h * 128 + 2 * (int64_t)lane;
+      // offsets r, r + 1, r + 2: the two rows of the pair (the last one is only read when the second row exists)
+      const int32_t o0 = offsets[r], o1 = offsets[r + 1];
+      const int32_t o2 = ((active >> (2 * h + 1)) & 1u) ? offsets[r + 2] : o1;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int32_t a0 = k ? o1 : o0, a1 = k ? o2 : o1;
+        bool same = ((active >> (2 * h + k)) & 1u) && (uint32_t)(a1 - a0) == len;
+        if (same) {
+          uint64_t w0 = 0, w1 = 0;
+          for (uint32_t i = 0; i < len; ++i) {  // uniform trip count
+            const uint64_t b = bytes[a0 + (int32_t)i];
+            if (i < 8) w0 |= b << (8 * i);
+            else w1 |= b << (8 * (i - 8));
+          }
+          same = w0 == lo && w1 == hi;
+        }
+        eq |= (same ? 1u : 0u) << (2 * h + k);
+      }
+    }
+  }
+  return eq;
+}
+
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   x ^= x >> 33;
   x *= 0xff51afd7ed558ccdull;
@@ -345,7 +378,7 @@ __device__ __forceinline__ void vm_binary_fast(uint32_t op, Slot &a, const Slot 
   a.valid &= b.valid;
 }
 
-__host__ __device__ constexpr bool op_is_fast_push(uint32_t op) { return op >= OP_PUSH_CACHED64 || op == OP_PUSH_LIT; }
+__host__ __device__ constexpr bool op_is_fast_push(uint32_t op) { return vm_op_is_cached_push(op) || op == OP_PUSH_LIT; }
 __host__ __device__ constexpr bool op_is_fast_binary(uint32_t op) {
   return (op >= OP_ADD_I32 && op <= OP_MUL_I32) || (op >= OP_ADD_I64 && op <= OP_MUL_I64) ||
          (op >= OP_ADD_F64 && op <= OP_MUL_F64) || (op >= OP_EQ_I64 && op <= OP_OR);
@@ -360,7 +393,7 @@ __device__ __forceinline__ void vm_slow(uint32_t op, uint32_t d, uint32_t arg, c
   c.n = c0.n;
   c.active = c0.active;
   c.lane = opaque(c0.lane);
-  const bool is_push = (op <= OP_PUSH_ROWID) || (op >= OP_UTF8_EQ_LIT && op <= OP_HASH_UTF8);
+  const bool is_push = (op <= OP_PUSH_ROWID) || (op >= OP_UTF8_EQ_LIT && op <= OP_HASH_UTF8) || op == OP_UTF8_EQ_LIT16 || op == OP_UTF8_NE_LIT16;
   const bool is_unary = op == OP_I64_TO_F64 || op == OP_MIX64;
   Slot a, b;
   uint32_t dst;
@@ -453,6 +486,17 @@ __device__ __forceinline__ void vm_slow(uint32_t op, uint32_t d, uint32_t arg, c
       uint32_t va = ca.validity ? load_bits4(ca.validity, c) : 0xFu;
       uint32_t vb = (!vs_lit && cb.validity) ? load_bits4(cb.validity, c) : 0xFu;
       a.valid = va & vb;
+      break;
+    }
+    case OP_UTF8_EQ_LIT16:
+    case OP_UTF8_NE_LIT16: {
+      const VmCol &ca = P.cols[arg & 0xffu];
+      const uint32_t li = (arg >> 8) & 0xffu;
+      const uint32_t eq = utf8_equals_lit16(ca.offsets, (const uint8_t *)ca.values, P.lits[li], P.lits[li + 1], (uint32_t)P.lits[li + 2], c.row0, c.lane, c.active);
+      const uint32_t bits = op == OP_UTF8_EQ_LIT16 ? eq : ~eq;
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) a.v[j] = (bits >> j) & 1u;
+      a.valid = ca.validity ? load_bits4(ca.validity, c) : 0xFu;
       break;
     }
     case OP_HASH_UTF8: {

@@ -824,14 +824,59 @@ __global__ void qe_scan_add_kernel(int32_t *data, int64_t n, const int32_t *bloc
     if (i < n) data[i] += off;
 }
 
-__global__ void qe_utf8_gather_bytes_kernel(const int32_t *src_offsets, const uint8_t *src_bytes, const int64_t *idx,
-                                            int64_t m, const int32_t *dst_offsets, uint8_t *dst_bytes) {
-  // one wave per 64 rows; each row's bytes copied by its lane
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = idx[i];
-    int32_t s0 = src_offsets[r], len = src_offsets[r + 1] - s0;
-    int32_t d0 = dst_offsets[i];
-    for (int32_t b = 0; b < len; ++b) dst_bytes[d0 + b] = src_bytes[s0 + b];
+// The bytes of the selected rows, a wave to every 64 output rows.  The output of those rows is one contiguous run of
+// bytes: the lanes walk it byte by byte, 64 consecutive bytes per store, and find each byte's row by a binary search
+// over the wave's 65 output offsets (LDS) - consecutive lanes read consecutive source bytes of a row.  (One lane per row
+// copying its bytes, as before, made every load and store of a wave touch 64 different cache lines.)
+constexpr int GATHER_WAVES = 4;
+__global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel(const int32_t *src_offsets, const uint8_t *src_bytes, const int64_t *idx,
+                                                                                    int64_t m, const int32_t *dst_offsets, uint8_t *dst_bytes) {
+  __shared__ int32_t s_dst[GATHER_WAVES][65];
+  __shared__ int32_t s_src[GATHER_WAVES][64];
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  const int64_t n_chunks = (m + 63) / 64;
+  for (int64_t chunk = (int64_t)blockIdx.x * GATHER_WAVES + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * GATHER_WAVES) {
+    const int64_t i = chunk * 64 + lane;
+    const int rows = (int)(m - chunk * 64 < 64 ? m - chunk * 64 : 64);
+    if (i < m) {
+      s_src[wave][lane] = src_offsets[idx[i]];
+      s_dst[wave][lane] = dst_offsets[i];
+    }
+    if (lane == 0) s_dst[wave][rows] = dst_offsets[chunk * 64 + rows];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's own LDS writes, before its reads below
+    __builtin_amdgcn_wave_barrier();
+    const int32_t d0 = s_dst[wave][0], d1 = s_dst[wave][rows];
+    // a lane takes four consecutive output bytes (one aligned dword store; the run's ragged ends go out byte by byte:
+    // the bytes next to them belong to other waves)
+    for (int32_t p4 = (d0 & ~3) + 4 * (int32_t)lane; p4 < d1; p4 += 256) {
+      const int32_t first = p4 < d0 ? d0 : p4;
+      int lo = 0, hi = rows;  // the last row q with s_dst[q] <= first (empty rows share their successor's offset)
+#pragma unroll
+      for (int step = 0; step < 7; ++step) {
+        const int mid = (lo + hi) >> 1;
+        if (hi - lo > 1) {
+          if (s_dst[wave][mid] <= first) lo = mid;
+          else hi = mid;
+        }
+      }
+      uint32_t word = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int32_t p = p4 + k;
+        if (p >= d0 && p < d1) {
+          while (s_dst[wave][lo + 1] <= p) ++lo;  // on to the row that holds byte p (skips empty rows)
+          word |= (uint32_t)src_bytes[s_src[wave][lo] + (p - s_dst[wave][lo])] << (8 * k);
+        }
+      }
+      if (p4 >= d0 && p4 + 4 <= d1) {
+        *(uint32_t *)(dst_bytes + p4) = word;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (p4 + k >= d0 && p4 + k < d1) dst_bytes[p4 + k] = (uint8_t)(word >> (8 * k));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the next chunk overwrites the offsets
   }
 }
 
@@ -925,7 +970,7 @@ __global__ void qe_generate_kernel(int kind, uint64_t seed, int64_t row0, int64_
 static bool program_needs_full(const VmProgram &P) {
   for (int i = 0; i < VM_MAX_INSN; ++i) {
     uint32_t op = P.insn[i] & 0xffu;
-    bool fast = op == OP_END || op == OP_PUSH_LIT || op >= OP_PUSH_CACHED64 || (op >= OP_ADD_I32 && op <= OP_MUL_I32) ||
+    bool fast = op == OP_END || op == OP_PUSH_LIT || vm_op_is_cached_push(op) || (op >= OP_ADD_I32 && op <= OP_MUL_I32) ||
                 (op >= OP_ADD_I64 && op <= OP_MUL_I64) || (op >= OP_ADD_F64 && op <= OP_MUL_F64) ||
                 (op >= OP_EQ_I64 && op <= OP_OR);
     if (!fast) return true;
@@ -1250,7 +1295,7 @@ hipError_t launch_exclusive_scan_i32(int32_t *data, int64_t n, int32_t *block_su
 hipError_t launch_utf8_gather_bytes(const int32_t *src_offsets, const uint8_t *src_bytes, const int64_t *idx, int64_t m,
                                     const int32_t *dst_offsets, uint8_t *dst_bytes, hipStream_t stream) {
   if (m <= 0) return hipSuccess;
-  hipLaunchKernelGGL(qe_utf8_gather_bytes_kernel, dim3(grid_for(m, 256, 4096)), dim3(256), 0, stream, src_offsets,
+  hipLaunchKernelGGL(qe_utf8_gather_bytes_kernel, dim3(grid_for(m, 256, 8192)), dim3(GATHER_WAVES * 64), 0, stream, src_offsets,
                      src_bytes, idx, m, dst_offsets, dst_bytes);
   return hipGetLastError();
 }

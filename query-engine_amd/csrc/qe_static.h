@@ -108,7 +108,7 @@ __device__ __forceinline__ void eval_static(const VmProgram &P, const RowCtx &c,
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) S[d].v[j] = l;
       S[d].valid = 0xFu;
-    } else if constexpr (op >= OP_PUSH_CACHED64) {
+    } else if constexpr (vm_op_is_cached_push(op)) {
       // the cache already holds decoded values (cache_load_static)
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) S[d].v[j] = K.v[arg][j];
@@ -136,6 +136,14 @@ __device__ __forceinline__ void eval_static(const VmProgram &P, const RowCtx &c,
     } else if constexpr (op == OP_I64_TO_F64) {
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) S[d - 1].v[j] = d2u((double)(int64_t)S[d - 1].v[j]);
+    } else if constexpr (op == OP_UTF8_EQ_LIT16 || op == OP_UTF8_NE_LIT16) {
+      const VmCol &col = P.cols[arg & 0xffu];
+      constexpr uint32_t li = (arg >> 8) & 0xffu;
+      const uint32_t eq = utf8_equals_lit16(col.offsets, (const uint8_t *)col.values, P.lits[li], P.lits[li + 1], (uint32_t)P.lits[li + 2], c.row0, c.lane, c.active);
+      const uint32_t bits = op == OP_UTF8_EQ_LIT16 ? eq : ~eq;
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) S[d].v[j] = (bits >> j) & 1u;
+      S[d].valid = col.validity ? load_bits4(col.validity, c) : 0xFu;
     } else if constexpr (op == OP_MIX64) {
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) S[d - 1].v[j] = mix64(S[d - 1].v[j]);

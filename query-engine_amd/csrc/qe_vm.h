@@ -57,10 +57,15 @@ enum VmOp : uint32_t {
   // pushes out of the per-step column cache (arg = cache slot)
   OP_PUSH_CACHED64, OP_PUSH_CACHED32, OP_PUSH_CACHEDBOOL,
   OP_MIX64,                        // top slot: 64-bit finaliser of a hash (composite group keys)
+  // utf8 column against a literal of at most 16 bytes, which travels in the program's literals instead of device memory:
+  // arg = col | lit<<8, lits[lit] = bytes 0..7, lits[lit+1] = bytes 8..15 (little endian), lits[lit+2] = length
+  OP_UTF8_EQ_LIT16, OP_UTF8_NE_LIT16,
   OP_COUNT_
 };
 
-// Instructions the shape-specialised kernels implement: everything except the utf8 comparisons and hash.
+constexpr bool vm_op_is_cached_push(uint32_t op) { return op >= OP_PUSH_CACHED64 && op <= OP_PUSH_CACHEDBOOL; }
+// Instructions the shape-specialised kernels implement: everything except the comparisons of a utf8 column with
+// another column or a long literal, and the utf8 hash.
 constexpr bool vm_op_specialisable(uint32_t op) { return op < OP_COUNT_ && !(op >= OP_UTF8_EQ_LIT && op <= OP_HASH_UTF8); }
 
 inline uint32_t vm_insn(uint32_t op, uint32_t depth, uint32_t arg) { return op | (depth << 8) | (arg << 12); }
