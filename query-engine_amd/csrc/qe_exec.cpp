@@ -489,14 +489,13 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
     ctx->prof_begin(kname, n);
     QE_HIP(launch_filter(args, ctx->dev, ctx->stream, &kname));
     ctx->prof_end(kname);
-    if (first) {
-      QE_HIP(hipMemcpyAsync(ctx->host_counters, scratch, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-      ctx->sync();
-      if (ctx->host_counters[2] != 0) fail(QE_ERR_INTERNAL, "filter look-back timed out");
-      m = n > 0 ? (int64_t)ctx->host_counters[1] : 0;
-    } else if (!comp.keepalive.empty()) {
-      ctx->sync();
-    }
+    // every pass runs the ticket / look-back protocol anew: each one's result words are read back (a look-back that
+    // timed out leaves rows unwritten)
+    QE_HIP(hipMemcpyAsync(ctx->host_counters, scratch, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    if (ctx->host_counters[2] != 0) fail(QE_ERR_INTERNAL, "filter look-back timed out");
+    if (first) m = n > 0 ? (int64_t)ctx->host_counters[1] : 0;
+    else if (n > 0 && (int64_t)ctx->host_counters[1] != m) fail(QE_ERR_INTERNAL, "filter passes selected different numbers of rows");
     first = false;
   }
   out.rows = m;
