@@ -507,6 +507,18 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
           {"groups": out.num_rows, "host_sync": "per aggregate (group count read back, exact-size output)"})
     del out
 
+    # The same plan with order-independent sums (QE_FLAG_DETERMINISTIC_SUM: same bits run after run): an extra pass over
+    # the value columns per batch finds the scale, four integer accumulators replace the float one.  What it costs.
+    ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_DETERMINISTIC_SUM | qe.FLAG_JIT_SYNC)
+    dt, prof, out = timed(ctx, torch, headline_default, 5, 2)
+    sums_1 = out.columns()[1].values.tobytes()
+    sums_2 = headline_default().columns()[1].values.tobytes()
+    entry("C5_headline_deterministic_sum", n, dt, prof, "qe_aggregate", BYTES_PER_ROW["c5"], len(hb),
+          {"groups": out.num_rows, "same_bits_on_a_second_run": sums_1 == sums_2,
+           "host_sync": "per batch (the scale pass) and per aggregate"})
+    ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP)
+    del out
+
     # A shape no kernel was built for ahead of time: key in column 2, predicate c < 0.3, value a*b - c.  The run-time
     # compiler specialises it (QE_FLAG_JIT_SYNC: compile on first use, here during the warm-up steps).
     rj = min(n, 500_000_000)

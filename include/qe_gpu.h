@@ -124,7 +124,18 @@ enum {
    * `group_capacity_hint` cannot be regrown in this mode: the failure is
    * reported by the next qe_context_synchronize (QE_ERR_AGG_CAPACITY).  No
    * counterpart in the reference. */
-  QE_FLAG_DEFERRED_GROUP_COUNT = 8
+  QE_FLAG_DEFERRED_GROUP_COUNT = 8,
+  /* Float64 SUM and AVG give the same bits for the same batches whatever order
+   * the device meets the rows in (by default the sums are folded with atomic
+   * adds in an order that changes from run to run; the reference folds them
+   * row by row in input order, physical_plan/mod.rs:340-372).  Every
+   * value is turned into a 96-bit fixed-point integer below a power of two that
+   * bounds the batch's values (found by an extra pass over the input columns),
+   * the integers are summed exactly, and one rounding happens at the end: the
+   * result is within rows * 2^-87 * max|value| of the exact sum.  Costs the
+   * extra pass, four integer accumulators per sum and a wait per batch; at most
+   * 2^31 rows per aggregate. */
+  QE_FLAG_DETERMINISTIC_SUM = 16
 };
 
 typedef struct qe_context qe_context;

@@ -258,6 +258,15 @@ ExprPtr make_key_hash(ExprPtr before, ExprPtr column) {
   return n;
 }
 
+ExprPtr make_fix(int part, ExprPtr value, int scale) {
+  auto n = std::make_shared<Expr>();
+  n->kind = EK_BINARY;
+  n->fix = part;
+  n->ival = scale;
+  n->l = std::move(value);
+  return n;
+}
+
 ExprPtr make_rowid(int64_t base) {
   auto n = std::make_shared<Expr>();
   n->kind = EK_ROWID;
@@ -301,6 +310,7 @@ std::string expr_to_string(const ExprPtr &e) {
       break;
     case EK_BINARY:
       if (e->to_f64) { o << "float64(" << expr_to_string(e->l) << ")"; break; }
+      if (e->fix) { o << "fix" << e->fix << "(" << expr_to_string(e->l) << ", " << e->ival << ")"; break; }
       o << expr_to_string(e->l) << " " << op_symbol(e->op) << " " << expr_to_string(e->r);
       break;
     case EK_HASH_UTF8: o << "hash(" << expr_to_string(e->l) << ")"; break;
@@ -333,6 +343,7 @@ std::string expr_identity(const ExprPtr &e) {
       break;
     case EK_BINARY:
       if (e->to_f64) o << "f64(" << expr_identity(e->l) << ")";
+      else if (e->fix) o << "fix" << e->fix << "(" << expr_identity(e->l) << "," << e->ival << ")";
       else o << "(" << expr_identity(e->l) << " " << e->op << " " << expr_identity(e->r) << ")";
       break;
     case EK_HASH_UTF8: o << "hash(" << expr_identity(e->l) << ")"; break;
@@ -349,7 +360,7 @@ bool expr_is_scalar(const ExprPtr &e) {
     case EK_HASH_UTF8:
     case EK_KEY_HASH:
     case EK_ROWID: return false;
-    default: return expr_is_scalar(e->l) && (e->to_f64 || expr_is_scalar(e->r));
+    default: return expr_is_scalar(e->l) && (e->to_f64 || e->fix || expr_is_scalar(e->r));
   }
 }
 
@@ -384,6 +395,10 @@ int expr_type(const ExprPtr &e, const Schema &schema) {
           fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, std::string("Physical type `") + type_name(lt) + "` is not supported.");
         return QE_TYPE_FLOAT64;
       }
+      if (e->fix) {
+        if (lt != QE_TYPE_FLOAT64) fail(QE_ERR_INTERNAL, "fixed-point image of something that is not Float64");
+        return QE_TYPE_INT64;
+      }
       int rt = expr_type(e->r, schema);
       if (lt != rt)
         fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, std::string("Physical type `") + type_name(lt) + "` is not supported (operands of `" +
@@ -417,7 +432,7 @@ bool expr_nullable(const ExprPtr &e, const Schema &schema) {
     case EK_KEY_HASH: return (e->l && expr_nullable(e->l, schema)) || expr_nullable(e->r, schema);
     case EK_ROWID: return false;
     default: {
-      if (e->to_f64) return expr_nullable(e->l, schema);
+      if (e->to_f64 || e->fix) return expr_nullable(e->l, schema);
       bool n = expr_nullable(e->l, schema) || expr_nullable(e->r, schema);
       if ((e->op == QE_OP_DIV || e->op == QE_OP_MOD) && expr_type(e->l, schema) != QE_TYPE_FLOAT64) n = true;
       return n;
@@ -525,6 +540,11 @@ ExprPtr expr_normalize(const ExprPtr &e, uint32_t flags) {
     n->l = l;
     return n;
   }
+  if (e->fix) {  // (not folded over a literal: the kernels compute it)
+    auto n = std::make_shared<Expr>(*e);
+    n->l = l;
+    return n;
+  }
   ExprPtr r = expr_normalize(e->r, flags);
   if (l->kind == EK_LITERAL && r->kind == EK_LITERAL) return fold_scalar(e->op, l, r);
   // (Scalar, Array): the reference calls `array OP scalar` (physical_expressions.rs:264-268)
@@ -573,9 +593,10 @@ ExprCost expr_cost(const ExprPtr &e, const Schema &schema) {
     }
     default: break;
   }
-  if (e->to_f64) {
+  if (e->to_f64 || e->fix) {
     c = expr_cost(e->l, schema);
     c.insns += 1;
+    if (e->fix >= FIX_LIMB0 && e->fix <= FIX_LIMB2) c.lits += 1;
     return c;
   }
   if (expr_type(e->l, schema) == QE_TYPE_UTF8) {  // one comparison instruction; a literal operand is (address, length)
@@ -744,6 +765,16 @@ void Compiler::emit(const ExprPtr &e, int depth) {
   if (e->to_f64) {
     emit(e->l, depth);
     if (expr_type(e->l, schema) != QE_TYPE_FLOAT64) push_insn(OP_I64_TO_F64, depth + 1, 0);
+    return;
+  }
+  if (e->fix) {
+    (void)expr_type(e, schema);
+    emit(e->l, depth);
+    switch (e->fix) {
+      case FIX_EXPONENT: push_insn(OP_FIX_EXP, depth + 1, 0); break;
+      case FIX_SPECIAL: push_insn(OP_FIX_SPECIAL, depth + 1, 0); break;
+      default: push_insn(OP_FIX_LIMB0 + (uint32_t)(e->fix - FIX_LIMB0), depth + 1, (uint32_t)lit_slot((uint64_t)e->ival)); break;
+    }
     return;
   }
   int lt = expr_type(e->l, schema);

@@ -144,6 +144,10 @@ struct Expr {
   std::string sval;    // UTF8 payload
   int op = 0;          // EK_BINARY: QE_OP_*
   bool to_f64 = false; // EK_BINARY unused; internal cast marker (AVG over integers)
+  // internal, made by the aggregate lowering for order-independent sums: a unary node over the float64 `l`
+  // (FIX_EXPONENT: its exponent field; FIX_LIMB0 + k: limb k of its fixed-point image at scale `ival`; FIX_SPECIAL:
+  // infinity / NaN marks), of type Int64
+  int fix = 0;
   ExprPtr l, r;
 };
 
@@ -162,6 +166,8 @@ ExprPtr make_binary(int op, ExprPtr l, ExprPtr r);
 ExprPtr make_hash_utf8(ExprPtr column);
 ExprPtr make_key_hash(ExprPtr before, ExprPtr column);
 ExprPtr make_rowid(int64_t base);
+enum FixPart { FIX_NONE = 0, FIX_EXPONENT = 1, FIX_LIMB0 = 2, FIX_LIMB1 = 3, FIX_LIMB2 = 4, FIX_SPECIAL = 5 };
+ExprPtr make_fix(int part, ExprPtr value, int scale);
 std::string expr_to_string(const ExprPtr &e);
 std::string expr_identity(const ExprPtr &e);  // equal exactly for equal trees (expr_to_string is the reference's ambiguous Display)
 bool expr_is_scalar(const ExprPtr &e);

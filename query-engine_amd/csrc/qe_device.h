@@ -378,6 +378,62 @@ __device__ __forceinline__ void vm_binary_fast(uint32_t op, Slot &a, const Slot 
   a.valid &= b.valid;
 }
 
+// ---- order-independent float64 sums (OP_FIX_*, FIN_FIX_*)
+// Limb `k` of trunc(|x| * 2^(96 - S)), with the sign of x.  |x| < 2^S is the caller's business (S comes from a pass
+// over the same rows); a value that breaks it loses its top bits instead of spilling into another limb's range.
+__device__ __forceinline__ uint64_t fix_limb(uint64_t bits, int S, int k) {
+  const uint32_t e = (uint32_t)(bits >> 52) & 0x7ffu;
+  if (e == 0x7ffu) return 0;
+  uint64_t m = bits & 0xfffffffffffffull;
+  if (e != 0) m |= 1ull << 52;
+  const int ee = e != 0 ? (int)e : 1;  // |x| = m * 2^(ee - 1075)
+  const int s = ee - (1075 - FIX_FRACTION_BITS) - S - 32 * k;
+  uint64_t v = s >= 0 ? (s < 64 ? m << s : 0) : (s > -64 ? m >> (-s) : 0);
+  v &= 0xffffffffull;
+  return (bits >> 63) ? 0 - v : v;
+}
+__device__ __forceinline__ uint64_t fix_exponent(uint64_t bits) {
+  const uint32_t e = (uint32_t)(bits >> 52) & 0x7ffu;
+  return e == 0x7ffu ? 0 : e;
+}
+__device__ __forceinline__ uint64_t fix_special(uint64_t bits) {
+  if (((bits >> 52) & 0x7ffu) != 0x7ffu) return 0;
+  if (bits & 0xfffffffffffffull) return 1ull | (1ull << 32);
+  return (bits >> 63) ? 1ull << 32 : 1ull;
+}
+// The float64 nearest to (l0 + l1 * 2^32 + l2 * 2^64) * 2^(S - 96); `special` as OP_FIX_SPECIAL counts it.
+__device__ __forceinline__ double fix_combine(uint64_t l0, uint64_t l1, uint64_t l2, uint64_t special, int S) {
+  const uint32_t pos = (uint32_t)special, neg = (uint32_t)(special >> 32);
+  if (pos && neg) return u2d(0x7ff8000000000000ull);
+  if (pos) return u2d(0x7ff0000000000000ull);
+  if (neg) return u2d(0xfff0000000000000ull);
+  __int128 t = (__int128)(int64_t)l0 + (((__int128)(int64_t)l1) << 32) + (((__int128)(int64_t)l2) << 64);
+  const bool negative = t < 0;
+  unsigned __int128 u = negative ? (unsigned __int128)(-t) : (unsigned __int128)t;
+  const uint64_t hi = (uint64_t)(u >> 64), lo = (uint64_t)u;
+  if (hi == 0 && lo == 0) return 0.0;
+  int shift = 0;
+  uint64_t top = lo;
+  if (hi != 0) {
+    shift = 64 - __builtin_clzll(hi);  // bits above the low word
+    top = (uint64_t)(u >> shift);
+    if ((u & ((((unsigned __int128)1) << shift) - 1)) != 0) top |= 1ull;  // sticky: the one rounding happens in the conversion below
+  }
+  const double d = ldexp((double)top, shift + S - FIX_FRACTION_BITS);
+  return negative ? -d : d;
+}
+// The limbs of a sum moved to a scale `delta` bits up (the sum's low bits beyond the new unit are cut off).
+__device__ __forceinline__ void fix_rescale(uint64_t &l0, uint64_t &l1, uint64_t &l2, int delta) {
+  __int128 t = (__int128)(int64_t)l0 + (((__int128)(int64_t)l1) << 32) + (((__int128)(int64_t)l2) << 64);
+  const bool negative = t < 0;
+  unsigned __int128 u = negative ? (unsigned __int128)(-t) : (unsigned __int128)t;
+  u = delta >= 128 ? 0 : u >> delta;
+  const uint64_t a = (uint64_t)u & 0xffffffffull, b = (uint64_t)(u >> 32) & 0xffffffffull, c = (uint64_t)(u >> 64);
+  l0 = negative ? 0 - a : a;
+  l1 = negative ? 0 - b : b;
+  l2 = negative ? 0 - c : c;
+}
+
 __host__ __device__ constexpr bool op_is_fast_push(uint32_t op) { return vm_op_is_cached_push(op) || op == OP_PUSH_LIT; }
 __host__ __device__ constexpr bool op_is_fast_binary(uint32_t op) {
   return (op >= OP_ADD_I32 && op <= OP_MUL_I32) || (op >= OP_ADD_I64 && op <= OP_MUL_I64) ||
@@ -394,7 +450,7 @@ __device__ __forceinline__ void vm_slow(uint32_t op, uint32_t d, uint32_t arg, c
   c.active = c0.active;
   c.lane = opaque(c0.lane);
   const bool is_push = (op <= OP_PUSH_ROWID) || (op >= OP_UTF8_EQ_LIT && op <= OP_HASH_UTF8) || op == OP_UTF8_EQ_LIT16 || op == OP_UTF8_NE_LIT16;
-  const bool is_unary = op == OP_I64_TO_F64 || op == OP_MIX64;
+  const bool is_unary = op == OP_I64_TO_F64 || op == OP_MIX64 || vm_op_is_fix(op);
   Slot a, b;
   uint32_t dst;
   if (is_push) {
@@ -531,6 +587,24 @@ __device__ __forceinline__ void vm_slow(uint32_t op, uint32_t d, uint32_t arg, c
     case OP_MIX64: {
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) a.v[j] = mix64(a.v[j]);
+      break;
+    }
+    case OP_FIX_EXP: {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) a.v[j] = fix_exponent(a.v[j]);
+      break;
+    }
+    case OP_FIX_LIMB0:
+    case OP_FIX_LIMB1:
+    case OP_FIX_LIMB2: {
+      const int S = (int)(int64_t)P.lits[arg];
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) a.v[j] = fix_limb(a.v[j], S, (int)(op - OP_FIX_LIMB0));
+      break;
+    }
+    case OP_FIX_SPECIAL: {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) a.v[j] = fix_special(a.v[j]);
       break;
     }
     case OP_DIV_F64: {

@@ -7,6 +7,7 @@
 // child (:167-170, :240-243, :293-296); Aggregate is eager and yields exactly
 // one batch (:274-283).
 #include <algorithm>
+#include <climits>
 #include <cstring>
 #include <functional>
 #include <sstream>
@@ -539,6 +540,7 @@ struct AggSpec {
     int out, col, type;
   };
   std::vector<KeyGather> key_gathers;
+  std::vector<int> agg_first_out;  // per aggregate: its (first) output column
 };
 
 static int add_acc(AggSpec &spec, uint8_t op, int in_type, bool track_nn, const ExprPtr &input) {
@@ -598,9 +600,21 @@ static bool key_tuple_hashed(const std::vector<int> &types) {
   return types.size() > 1 && (strings > 0 || total_bits > 64 || (int)types.size() > VM_MAX_KEYS);
 }
 
+// An order-independent Float64 sum of `x` at scale `S`: three integer sums of the limbs of x's fixed-point image and
+// one of its infinity / NaN marks, in consecutive accumulators; the first one's index.
+static int add_fix_sum(AggSpec &spec, const ExprPtr &x, int S, bool track_nn) {
+  const int a = add_acc(spec, ACC_SUM_I64, QE_TYPE_INT64, track_nn, make_fix(FIX_LIMB0, x, S));
+  const int b = add_acc(spec, ACC_SUM_I64, QE_TYPE_INT64, false, make_fix(FIX_LIMB1, x, S));
+  const int c = add_acc(spec, ACC_SUM_I64, QE_TYPE_INT64, false, make_fix(FIX_LIMB2, x, S));
+  const int d = add_acc(spec, ACC_SUM_I64, QE_TYPE_INT64, false, make_fix(FIX_SPECIAL, x, 0));
+  if (b != a + 1 || c != a + 2 || d != a + 3) fail(QE_ERR_INTERNAL, "the accumulators of an order-independent sum are not consecutive");
+  return a;
+}
+
+// `fix_scales`: per aggregate the scale of its order-independent sum (QE_FLAG_DETERMINISTIC_SUM), or null.
 static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::vector<ExprPtr> &groups,
                               const std::vector<AggExpr> &aggs, const std::vector<ExprPtr> &aggs_second, int mode,
-                              int64_t row_base = 0, bool emit_row_number = false) {
+                              int64_t row_base = 0, bool emit_row_number = false, const std::vector<int> *fix_scales = nullptr) {
   AggSpec spec;
   int shift = 0;
   if ((int)groups.size() > MAX_HASHED_KEYS) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many group expressions.");
@@ -677,6 +691,7 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
   }
   for (size_t i = 0; i < aggs.size(); ++i) {
     const AggExpr &ag = aggs[i];
+    spec.agg_first_out.push_back((int)spec.outs.size());
     ExprPtr e = ag.input ? expr_normalize(ag.input, flags) : nullptr;
     int t = e ? expr_type(e, schema) : 0;
     bool nullable = e ? expr_nullable(e, schema) : false;
@@ -700,6 +715,13 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
       case QE_AGG_SUM: {
         need_numeric();
         bool f64 = t == QE_TYPE_FLOAT64;
+        if (f64 && fix_scales) {
+          const int a = add_fix_sum(spec, e, (*fix_scales)[i], nullable);
+          FinOut f = fin(FIN_FIX_SUM, t, a, a, CNT_NN, nullable ? NULL_IF_COUNT_ZERO : NULL_NEVER);
+          f.scale = (int16_t)(*fix_scales)[i];
+          spec.outs.push_back(f);
+          break;
+        }
         int a = add_acc(spec, f64 ? ACC_SUM_F64 : ACC_SUM_I64, t, nullable, e);
         spec.outs.push_back(fin(f64 ? FIN_ACC_F64 : FIN_ACC_I64, t, a, a, CNT_NN, nullable ? NULL_IF_COUNT_ZERO : NULL_NEVER));
         break;
@@ -722,25 +744,31 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
           ExprPtr cnt_e = aggs_second[i] ? expr_normalize(aggs_second[i], flags) : nullptr;
           if (!e || t != QE_TYPE_FLOAT64 || !cnt_e || expr_type(cnt_e, schema) != QE_TYPE_INT64)
             fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "AVG partial columns must be (Float64 sum, Int64 count).");
-          int a = add_acc(spec, ACC_SUM_F64, QE_TYPE_FLOAT64, false, e);
+          int a = fix_scales ? add_fix_sum(spec, e, (*fix_scales)[i], false) : add_acc(spec, ACC_SUM_F64, QE_TYPE_FLOAT64, false, e);
           int b = add_acc(spec, ACC_SUM_I64, QE_TYPE_INT64, false, cnt_e);
-          spec.outs.push_back(fin(FIN_AVG, QE_TYPE_FLOAT64, a, b, CNT_ACC, NULL_IF_COUNT_ZERO));
+          FinOut f = fin(fix_scales ? FIN_FIX_AVG : FIN_AVG, QE_TYPE_FLOAT64, a, b, CNT_ACC, NULL_IF_COUNT_ZERO);
+          if (fix_scales) f.scale = (int16_t)(*fix_scales)[i];
+          spec.outs.push_back(f);
           break;
         }
         need_numeric();
-        int a = add_acc(spec, ACC_SUM_F64, QE_TYPE_FLOAT64, false, make_to_f64(e));
+        int a = fix_scales ? add_fix_sum(spec, make_to_f64(e), (*fix_scales)[i], false)
+                           : add_acc(spec, ACC_SUM_F64, QE_TYPE_FLOAT64, false, make_to_f64(e));
         int b = -1;
         uint8_t src = CNT_ROWS;
         if (nullable) {
           b = add_acc(spec, ACC_COUNT, t, false, e);
           src = CNT_ACC;
         }
+        FinOut f;
         if (mode == QE_AGG_MODE_PARTIAL) {
-          spec.outs.push_back(fin(FIN_ACC_F64, QE_TYPE_FLOAT64, a, a, CNT_ROWS, NULL_NEVER));
-          spec.outs.push_back(fin(FIN_COUNT, QE_TYPE_INT64, b < 0 ? 0 : b, b < 0 ? 0 : b, src, NULL_NEVER));
+          f = fin(fix_scales ? FIN_FIX_SUM : FIN_ACC_F64, QE_TYPE_FLOAT64, a, a, CNT_ROWS, NULL_NEVER);
         } else {
-          spec.outs.push_back(fin(FIN_AVG, QE_TYPE_FLOAT64, a, b < 0 ? 0 : b, src, NULL_IF_COUNT_ZERO));
+          f = fin(fix_scales ? FIN_FIX_AVG : FIN_AVG, QE_TYPE_FLOAT64, a, b < 0 ? 0 : b, src, NULL_IF_COUNT_ZERO);
         }
+        if (fix_scales) f.scale = (int16_t)(*fix_scales)[i];
+        spec.outs.push_back(f);
+        if (mode == QE_AGG_MODE_PARTIAL) spec.outs.push_back(fin(FIN_COUNT, QE_TYPE_INT64, b < 0 ? 0 : b, b < 0 ? 0 : b, src, NULL_NEVER));
         break;
       }
       default:
@@ -989,7 +1017,17 @@ struct AggState {
   std::vector<std::unique_ptr<AggState>> parts;
   bool emit_row_number = false;  // this is such a part
 
-  static int acc_weight(const AggExpr &a) { return a.kind == QE_AGG_AVG ? 2 : 1; }  // accumulators an aggregate may take
+  // Order-independent Float64 sums (QE_FLAG_DETERMINISTIC_SUM): the scale every such aggregate's limbs are at (INT_MIN:
+  // no value seen yet), the rows folded in so far, and - for the aggregate that finds a batch's scales - no deferral.
+  std::vector<int> fix_scale;
+  int64_t fix_rows = 0;
+  bool no_defer = false;
+  bool fix_wanted() const { return (ctx->flags & QE_FLAG_DETERMINISTIC_SUM) != 0; }
+
+  int acc_weight(const AggExpr &a) const {  // accumulators an aggregate may take
+    const bool fix = fix_wanted();
+    return a.kind == QE_AGG_AVG ? (fix ? FIX_ACCS + 1 : 2) : (fix && a.kind == QE_AGG_SUM ? FIX_ACCS : 1);
+  }
   static constexpr int PART_ACC_BUDGET = VM_MAX_ACCS - 2;                           // the row number, and one to spare
 
   // What the kernels' choices (LDS table size, high-cardinality mode) go by: the caller's group-count hint, or -
@@ -1032,6 +1070,50 @@ struct AggState {
     table_buf.reset();
     key_sources.clear();
     row_base = 0;
+    fix_scale.clear();
+    fix_rows = 0;
+  }
+
+  // The scale each order-independent sum needs for this batch: the smallest multiple of 8 with |value| < 2^scale for
+  // every finite input the predicate lets through (INT_MIN when there is none), found by a keyless MAX over the
+  // inputs' exponent fields.
+  std::vector<int> batch_scales(const Batch &in_raw, const std::vector<ExprPtr> &outputs, const ExprPtr &pred, const std::vector<char> &is_fix) {
+    std::vector<int> need(aggs.size(), INT_MIN);
+    if (in_raw.rows == 0) return need;
+    AggState probe;
+    probe.ctx = ctx;
+    probe.strict = strict;
+    probe.no_defer = true;
+    probe.cap_hint = 1;
+    std::vector<size_t> owner;
+    for (size_t i = 0; i < aggs.size(); ++i)
+      if (is_fix[i]) {
+        AggExpr m;
+        m.kind = QE_AGG_MAX;
+        m.input = make_fix(FIX_EXPONENT, mode == QE_AGG_MODE_FINAL ? aggs[i].input : make_to_f64(aggs[i].input), 0);
+        probe.aggs.push_back(m);
+        owner.push_back(i);
+      }
+    probe.start(1);
+    probe.update(in_raw, outputs, pred);
+    Batch r;
+    try {
+      if (!probe.finish(r)) fail(QE_ERR_INTERNAL, "the scale pass of an order-independent sum overflowed its table");
+    } catch (const Failure &f) {
+      if (f.code == QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE) return need;  // the predicate let nothing through
+      throw;
+    }
+    if (r.rows != 1 || r.cols.size() != owner.size()) fail(QE_ERR_INTERNAL, "the scale pass of an order-independent sum found more than one group");
+    std::vector<int64_t> e(owner.size(), 0);
+    std::vector<uint8_t> v(owner.size(), 1);
+    for (size_t j = 0; j < owner.size(); ++j) {
+      QE_HIP(hipMemcpyAsync(&e[j], r.cols[j].values_ptr(), 8, hipMemcpyDeviceToHost, ctx->stream));
+      if (r.cols[j].validity) QE_HIP(hipMemcpyAsync(&v[j], r.cols[j].validity_ptr(), 1, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ctx->sync();
+    for (size_t j = 0; j < owner.size(); ++j)
+      if (v[j] & 1u) need[owner[j]] = (int)((std::max<int64_t>(e[j], 1) - 1022 + 7) & ~(int64_t)7);
+    return need;
   }
 
   // Folds one batch in.  `outputs` (may be empty = the batch's columns) are the expressions the
@@ -1063,16 +1145,53 @@ struct AggState {
     }
     Schema schema = schema_of(in);
     ExprPtr pred_n = pred ? expr_normalize(pred, ctx->flags) : nullptr;
+    // order-independent sums: this batch's scales first (a pass of its own), the table's limbs moved up where needed
+    std::vector<char> is_fix(aggs.size(), 0);
+    bool any_fix = false;
+    if (fix_wanted())
+      for (size_t i = 0; i < a2.size(); ++i)
+        if (a2[i].input && (a2[i].kind == QE_AGG_AVG || (a2[i].kind == QE_AGG_SUM && expr_type(expr_normalize(a2[i].input, ctx->flags), schema) == QE_TYPE_FLOAT64))) {
+          const int t = expr_type(expr_normalize(a2[i].input, ctx->flags), schema);
+          if (!numeric(t)) continue;  // (build_agg_spec reports it)
+          is_fix[i] = 1;
+          any_fix = true;
+        }
+    std::vector<int> scales_now;
+    if (any_fix) {
+      fix_rows += in.rows;
+      if (fix_rows > ((int64_t)1 << 31)) fail(QE_ERR_INVALID_ARGUMENT, "QE_FLAG_DETERMINISTIC_SUM: more than 2^31 rows in one aggregate");
+      if (fix_scale.empty()) fix_scale.assign(aggs.size(), INT_MIN);
+      const std::vector<int> need = batch_scales(in_raw, outputs, pred, is_fix);
+      std::vector<int> moved;
+      for (size_t i = 0; i < aggs.size(); ++i) {
+        if (!is_fix[i] || need[i] <= fix_scale[i]) continue;
+        if (have_table && fix_scale[i] != INT_MIN) {
+          const int acc = spec.outs[(size_t)spec.agg_first_out[i]].a;
+          if (std::find(moved.begin(), moved.end(), acc) == moved.end()) {
+            moved.push_back(acc);
+            ctx->prof_begin("qe_fix_rescale_kernel");
+            QE_HIP(launch_fix_rescale(table, acc, need[i] - fix_scale[i], ctx->stream));
+            ctx->prof_end();
+          }
+        }
+        fix_scale[i] = need[i];
+      }
+      for (size_t i = 0; i < aggs.size(); ++i) scales_now.push_back(fix_scale[i] == INT_MIN ? 0 : fix_scale[i]);
+    }
     {
       // predicate, keys and accumulator inputs share one program: whatever exceeds it is evaluated beforehand
       std::vector<ExprPtr *> all;
       if (pred_n) all.push_back(&pred_n);
       for (auto &g : g2) all.push_back(&g);
-      for (auto &a : a2)
+      for (size_t i = 0; i < a2.size(); ++i) {
+        AggExpr &a = a2[i];
         if (a.input) {
           all.push_back(&a.input);
           if (a.kind == QE_AGG_AVG) all.push_back(&a.input);  // its sum and its count each evaluate the input
+          if (is_fix[i])
+            for (int k = 1; k < FIX_ACCS; ++k) all.push_back(&a.input);  // and so does every limb of an order-independent sum
         }
+      }
       for (ExprPtr *p : all) {
         *p = expr_normalize(*p, ctx->flags);
         (void)expr_type(*p, schema);
@@ -1087,7 +1206,7 @@ struct AggState {
       fitter.fit_together(all, 12 + 5 * (int)g2.size() + (int)a2.size(), 4);
       if (fitter.temporaries) schema = fitter.schema;
     }
-    AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode, row_base, emit_row_number);
+    AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode, row_base, emit_row_number, any_fix ? &scales_now : nullptr);
     key_sources.resize(bspec.key_gathers.size());
     for (size_t i = 0; i < bspec.key_gathers.size(); ++i) key_sources[i].push_back(Utf8KeySource{in.cols[bspec.key_gathers[i].col], row_base});
     row_base += in.rows;
@@ -1128,6 +1247,7 @@ struct AggState {
         if (!strict) throw NeedsStrictNullability{};
         fail(QE_ERR_INVALID_ARGUMENT, "batches of one scan must share a schema");
       }
+      for (size_t i = 0; same && i < spec.outs.size() && i < bspec.outs.size(); ++i) spec.outs[i].scale = bspec.outs[i].scale;
       // a later batch may be nullable where the first was not: keep the stricter tracking
       for (size_t i = 0; i < spec.accs.size(); ++i)
         if (bspec.accs[i].acc.track_nn && !spec.accs[i].acc.track_nn) {
@@ -1168,7 +1288,7 @@ struct AggState {
     return total;
   }
   bool deferred_wanted() const {
-    return table.cap + 1 <= (1u << 16) && (ctx->flags & QE_FLAG_DEFERRED_GROUP_COUNT) && spec.key_gathers.empty() && !emit_row_number;
+    return table.cap + 1 <= (1u << 16) && (ctx->flags & QE_FLAG_DEFERRED_GROUP_COUNT) && spec.key_gathers.empty() && !emit_row_number && !no_defer;
   }
 
   bool finish_deferred(Batch &result) {
@@ -1525,7 +1645,9 @@ static void for_each_lowered_launch(const Schema &schema, uint32_t flags, const 
       }
       second.push_back(sec);
     }
-    AggSpec spec = build_agg_spec(flags, schema, g2, a2, second, mode);
+    // (order-independent sums: the launch has the same shape at every scale)
+    const std::vector<int> scales(a2.size(), 0);
+    AggSpec spec = build_agg_spec(flags, schema, g2, a2, second, mode, 0, false, (flags & QE_FLAG_DETERMINISTIC_SUM) ? &scales : nullptr);
     Compiler comp(nullptr, &in);
     AggArgs args{};
     lower_aggregate(comp, schema, pred, spec, spec, args);

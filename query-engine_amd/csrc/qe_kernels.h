@@ -55,6 +55,8 @@ int aggregate_grid(const AggArgs &args, const DeviceInfo &dev);
 hipError_t launch_table_init(const AggTable &table, const VmAcc *accs, int n_accs, hipStream_t stream, void *zero = nullptr, size_t zero_bytes = 0);
 // Compact occupied slots into output columns.
 hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream);
+// Moves the limbs of the order-independent sum in accumulators acc .. acc+2 to a scale `delta` bits up.
+hipError_t launch_fix_rescale(const AggTable &table, int acc, int delta, hipStream_t stream);
 
 // utf8 helpers: gather rows `idx[0..m)` of a utf8 column.
 hipError_t launch_utf8_gather_lengths(const int32_t *offsets, const uint8_t *validity, const int64_t *idx, int64_t m,

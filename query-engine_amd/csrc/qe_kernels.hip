@@ -606,6 +606,31 @@ __global__ void qe_table_init_kernel(AggTable T, uint64_t packed_lo, uint64_t pa
   if (blockIdx.x == 0 && threadIdx.x < 8) T.ctrl[threadIdx.x] = 0;
 }
 
+// Order-independent sums at output time (FIN_FIX_SUM / FIN_FIX_AVG).
+__device__ __forceinline__ double fin_fix_sum(const AggTable &T, const FinOut &f, uint64_t i) {
+  const unsigned long long *acc = T.acc + (uint64_t)f.a * T.stride + i;
+  return fix_combine(acc[0], acc[T.stride], acc[2 * T.stride], acc[3 * T.stride], (int)f.scale);
+}
+
+// The limbs of the sums in the table moved `delta` bits up: a later batch holds larger values than the scale so far allows.
+__global__ void qe_fix_rescale_kernel(AggTable T, int acc, int delta) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < T.stride; i += (uint64_t)gridDim.x * blockDim.x) {
+    unsigned long long *p = T.acc + (uint64_t)acc * T.stride + i;
+    uint64_t l0 = p[0], l1 = p[T.stride], l2 = p[2 * T.stride];
+    if ((l0 | l1 | l2) == 0) continue;
+    fix_rescale(l0, l1, l2, delta);
+    p[0] = l0;
+    p[T.stride] = l1;
+    p[2 * T.stride] = l2;
+  }
+}
+
+hipError_t launch_fix_rescale(const AggTable &table, int acc, int delta, hipStream_t stream) {
+  const uint64_t blocks = std::min<uint64_t>((table.stride + 255) / 256, 4096);
+  qe_fix_rescale_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(table, acc, delta);
+  return hipGetLastError();
+}
+
 // Small tables: one atomic per wave is few enough, and no barriers.
 __global__ __launch_bounds__(256) void qe_finalize_small_kernel(const FinalizeArgs A) {
   const AggTable &T = A.table;
@@ -651,6 +676,12 @@ __global__ __launch_bounds__(256) void qe_finalize_small_kernel(const FinalizeAr
           break;
         case FIN_AVG:
           val = valid ? d2u(u2d(T.acc[(uint64_t)f.a * T.stride + i]) / (double)cnt) : 0;
+          break;
+        case FIN_FIX_SUM:
+          val = d2u(fin_fix_sum(T, f, i));
+          break;
+        case FIN_FIX_AVG:
+          val = valid ? d2u(fin_fix_sum(T, f, i) / (double)cnt) : 0;
           break;
         default:
           break;
@@ -736,6 +767,12 @@ __global__ __launch_bounds__(256) void qe_finalize_kernel(const FinalizeArgs A) 
             break;
           case FIN_AVG:
             val = valid ? d2u(u2d(T.acc[(uint64_t)f.a * T.stride + i]) / (double)cnt) : 0;
+            break;
+          case FIN_FIX_SUM:
+            val = d2u(fin_fix_sum(T, f, i));
+            break;
+          case FIN_FIX_AVG:
+            val = valid ? d2u(fin_fix_sum(T, f, i) / (double)cnt) : 0;
             break;
           default:
             break;

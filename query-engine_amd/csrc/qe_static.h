@@ -147,6 +147,16 @@ __device__ __forceinline__ void eval_static(const VmProgram &P, const RowCtx &c,
     } else if constexpr (op == OP_MIX64) {
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) S[d - 1].v[j] = mix64(S[d - 1].v[j]);
+    } else if constexpr (op == OP_FIX_EXP) {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) S[d - 1].v[j] = fix_exponent(S[d - 1].v[j]);
+    } else if constexpr (op == OP_FIX_LIMB0 || op == OP_FIX_LIMB1 || op == OP_FIX_LIMB2) {
+      const int scale = (int)(int64_t)P.lits[arg];
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) S[d - 1].v[j] = fix_limb(S[d - 1].v[j], scale, (int)(op - OP_FIX_LIMB0));
+    } else if constexpr (op == OP_FIX_SPECIAL) {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) S[d - 1].v[j] = fix_special(S[d - 1].v[j]);
     } else if constexpr (op == OP_DIV_F64) {
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) S[d - 2].v[j] = d2u(u2d(S[d - 2].v[j]) / u2d(S[d - 1].v[j]));

@@ -60,6 +60,12 @@ enum VmOp : uint32_t {
   // utf8 column against a literal of at most 16 bytes, which travels in the program's literals instead of device memory:
   // arg = col | lit<<8, lits[lit] = bytes 0..7, lits[lit+1] = bytes 8..15 (little endian), lits[lit+2] = length
   OP_UTF8_EQ_LIT16, OP_UTF8_NE_LIT16,
+  // Order-independent float64 sums: a value becomes a 96-bit fixed-point integer in units of 2^(S - 96), S = lits[arg],
+  // whose three 32-bit limbs (signed like the value) are summed as integers by three accumulators; integer addition is
+  // associative, so the result does not depend on the order the rows meet the accumulators in.
+  OP_FIX_EXP,                      // top slot: float64 -> its biased exponent field as int64 (0 for infinities and NaN)
+  OP_FIX_LIMB0, OP_FIX_LIMB1, OP_FIX_LIMB2,  // top slot: float64 -> limb (0 for infinities and NaN); arg = literal index of S
+  OP_FIX_SPECIAL,                  // top slot: float64 -> 1 for +inf, 2^32 for -inf, both for NaN, 0 otherwise
   OP_COUNT_
 };
 
@@ -259,6 +265,10 @@ struct PartArgs {
   unsigned long long *ticket;      // zeroed before the launch
 };
 
+constexpr int FIX_FRACTION_BITS = 96;  // fixed-point digits below 2^S
+constexpr int FIX_ACCS = 4;            // accumulators of one order-independent sum: three limbs and the infinity / NaN counts
+constexpr bool vm_op_is_fix(uint32_t op) { return op >= OP_FIX_EXP && op <= OP_FIX_SPECIAL; }
+
 // One output column of the finalize pass.
 enum FinKind : uint8_t {
   FIN_KEY = 1,      // unpack key field -> values (type in `type`)
@@ -266,7 +276,9 @@ enum FinKind : uint8_t {
   FIN_ACC_F64 = 3,  // raw float64 accumulator
   FIN_ACC_ORD = 4,  // inverse of the order-preserving image (min / max)
   FIN_COUNT = 5,    // the count source itself
-  FIN_AVG = 6       // acc[a] (float64) / count source
+  FIN_AVG = 6,      // acc[a] (float64) / count source
+  FIN_FIX_SUM = 7,  // order-independent sum: limbs acc[a .. a+2] in units of 2^(scale - 96), acc[a+3] = infinity / NaN counts
+  FIN_FIX_AVG = 8   // that sum / count source
 };
 // Where a column's count comes from.
 enum FinCnt : uint8_t { CNT_ROWS = 0, CNT_NN = 1, CNT_ACC = 2 };
@@ -284,6 +296,8 @@ struct FinOut {
   uint8_t bits;        // FIN_KEY
   uint8_t cnt_src;     // FinCnt
   uint8_t null_mode;   // FinNull
+  int16_t scale;       // FIN_FIX_*: S
+  uint8_t pad[6];
 };
 
 struct FinalizeArgs {

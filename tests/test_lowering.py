@@ -85,6 +85,28 @@ def test_runtime_compilation_offline(qe):
     assert d["launches"][0]["specialisable"] == 0
 
 
+def test_order_independent_sum_lowering(qe):
+    """QE_FLAG_DETERMINISTIC_SUM: a Float64 SUM becomes four integer sums (three limbs of the value's fixed-point image
+    and its infinity / NaN marks), AVG the same plus its count; integer sums stay as they are; the run-time compiler
+    builds the shape."""
+    C, F = qe.ColumnExpression, qe.LiteralFloatExpression
+    i64, f64 = qe.TYPE_INT64, qe.TYPE_FLOAT64
+    flags = qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_DETERMINISTIC_SUM
+    plan = dict(predicate=qe.GtExpression(C(3), F(0.5)), exprs=[C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))],
+                group_exprs=[C(0)], agg_exprs=[qe.SumExpression(C(1)), qe.CountExpression(None)])
+    (launch,) = qe.describe_lowering([i64, f64, f64, f64], flags=flags, **plan)["launches"]
+    assert launch["accs"] == [{"op": 1, "type": i64, "track": 0, "has_input": 1}] * 4
+    assert launch["specialisable"] == 1
+    (plain,) = qe.describe_lowering([i64, f64, f64, f64], **plan)["launches"]
+    assert len(plain["accs"]) == 1 and plain["sig"] != launch["sig"]
+    (ints,) = qe.describe_lowering([i64, i64], flags=flags, group_exprs=[C(0)], agg_exprs=[qe.SumExpression(C(1))])["launches"]
+    assert ints["accs"] == [{"op": 1, "type": i64, "track": 0, "has_input": 1}]
+    (avg,) = qe.describe_lowering([i64, f64], [False, True], flags=flags, group_exprs=[C(0)], agg_exprs=[qe.AvgExpression(C(1))])["launches"]
+    assert [a["op"] for a in avg["accs"]] == [1, 1, 1, 1, 5]  # limbs, marks, COUNT(x)
+    nk, nb = qe.compile_lowering([i64, f64, f64, f64], flags=flags, **plan)
+    assert nk == 1 and nb > 4096
+
+
 def test_logical_expression_display(qe):
     """impl Display for LogicalExpression (logical_expression.rs:68-96, 123-127, 276-280, 378-382)."""
     P = qe.prelude
