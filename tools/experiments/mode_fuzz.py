@@ -19,7 +19,7 @@ from util import gpu_batch
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 ctx = qe.Context(0)
-BASE = qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP
+BASE = qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | (qe.FLAG_DETERMINISTIC_SUM if os.environ.get("QE_FUZZ_DET") == "1" else 0)
 ctx.set_flags(BASE)
 r = np.random.default_rng(seed0)
 bad = 0
