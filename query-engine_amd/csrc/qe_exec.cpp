@@ -878,6 +878,7 @@ static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &b
   }
   // Rows will miss the workgroups' tables in numbers: when a kernel specialised for the shape exists, one wide workgroup
   // per compute unit with a table of four times the slots (fewer rows in the log, the same waves in flight)
+  if (group_hint >= spill_min_group_hint()) args.tune |= 2u;
   if (aggregate_wide_available(args, ctx->dev)) {
     args.block_threads = AGG_WIDE_THREADS;
     args.lds_cap = aggregate_lds_slots(args, ctx->dev, 0, true);

@@ -18,7 +18,9 @@ enum JitMode : int {
   JIT_SYNC = 2    // compile on first use and wait (tests, prepared workloads)
 };
 
-enum JitKind : int { JIT_PROJECT = 0, JIT_FILTER = 1, JIT_AGGREGATE = 2 };
+// JIT_AGGREGATE_SPILL: the high-cardinality mode's first pass (qe_aggregate_spill_static) of an aggregate shape; its
+// SpecFields carry one more signature word than the plain aggregate's (spec_fields_spill), so the two never share an entry.
+enum JitKind : int { JIT_PROJECT = 0, JIT_FILTER = 1, JIT_AGGREGATE = 2, JIT_AGGREGATE_SPILL = 3 };
 
 // Launches the run-time compiled kernel for this shape if there is one (or, in JIT_SYNC mode,
 // after compiling it).  Returns false when the caller should use the interpreter instead: shape

@@ -93,7 +93,7 @@ hipError_t launch_count_zero_bits(const uint32_t *bitmap, int64_t n, unsigned lo
 bool static_launch_project(const ProjectArgs &args, int grid, hipStream_t stream, hipError_t *err, const char **kernel_name);
 bool static_launch_filter(const FilterArgs &args, int cus, hipStream_t stream, hipError_t *err, const char **kernel_name);
 bool static_launch_aggregate(const AggArgs &args, int grid, int block_threads, size_t lds_bytes, hipStream_t stream, hipError_t *err,
-                             const char **kernel_name);
+                             const char **kernel_name, bool spill_first_pass = false);
 bool static_has_aggregate(const AggArgs &args);
 int static_kernel_count();
 const char *static_kernel_name(int i);

@@ -1141,7 +1141,8 @@ bool aggregate_wide_available(const AggArgs &args, const DeviceInfo &dev) {
   static int enabled = tuned("QE_AGGREGATE_WIDE", 1);
   if (enabled == 2 || !dev.specialised) return false;
   if (static_has_aggregate(args)) return true;
-  return jit_wanted(dev, args.n_rows) && jit_ready(JIT_AGGREGATE, spec_fields(args), dev.jit);
+  if (!jit_wanted(dev, args.n_rows)) return false;
+  return (args.tune & 2u) ? jit_ready(JIT_AGGREGATE_SPILL, spec_fields_spill(args), dev.jit) : jit_ready(JIT_AGGREGATE, spec_fields(args), dev.jit);
 }
 
 // Dense-key bins (see qe_static.h) for aggregates with few groups whose inputs cannot be null, when
@@ -1170,8 +1171,20 @@ hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipSt
       args.door_off = (uint32_t)((lds + 15) & ~(size_t)15);
       lds = args.door_off + DOOR_ENTRIES * 2;
     }
-    if (static_launch_aggregate(args, grid, AGG_WIDE_THREADS, lds, stream, &werr, kernel_name)) return werr;
-    if (jit_launch(JIT_AGGREGATE, spec_fields(args), &args, dev.jit, dev.device, grid, AGG_WIDE_THREADS, lds, stream, &werr, kernel_name)) return werr;
+    // the wide launch is the high-cardinality mode's first pass: a kernel of its own (QE_AGGREGATE_SPILL_KERNEL=2: the
+    // general specialised kernel instead, for comparison)
+    // Mid-range cardinalities (a few thousand groups, possibly skewed) keep the general kernel, whose hot keys in
+    // registers take a dominant key off the LDS atomics.
+    static int lean = tuned("QE_AGGREGATE_SPILL_KERNEL", 1);
+    const bool many_groups = args.spill.keys != nullptr && (args.tune & 2u) != 0;
+    const bool spill_kernel = lean != 2 && many_groups;
+    if (many_groups && !spill_kernel) args.tune |= 1u;  // (with many groups the hot keys cost more than they save: 2.67 -> 2.42 ms per 256 M rows)
+    if (static_launch_aggregate(args, grid, AGG_WIDE_THREADS, lds, stream, &werr, kernel_name, spill_kernel)) return werr;
+    if (spill_kernel) {
+      if (jit_launch(JIT_AGGREGATE_SPILL, spec_fields_spill(args), &args, dev.jit, dev.device, grid, AGG_WIDE_THREADS, lds, stream, &werr, kernel_name)) return werr;
+    } else if (jit_launch(JIT_AGGREGATE, spec_fields(args), &args, dev.jit, dev.device, grid, AGG_WIDE_THREADS, lds, stream, &werr, kernel_name)) {
+      return werr;
+    }
     return hipErrorInvalidConfiguration;
   }
   if (dev.specialised && dense_bins_wanted(args, lds, grid, dev)) {

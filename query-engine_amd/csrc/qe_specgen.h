@@ -130,4 +130,11 @@ inline SpecFields spec_fields(const AggArgs &A) {
   return f;
 }
 
+// The same shape as the first pass of the high-cardinality mode: a kernel of its own, an entry of its own.
+inline SpecFields spec_fields_spill(const AggArgs &A) {
+  SpecFields f = spec_fields(A);
+  f.sig.push_back(0x5104u);
+  return f;
+}
+
 }  // namespace qe

@@ -628,7 +628,7 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, spec_min_waves_per_simd<Spec>()) 
   HotCache<Spec::n_accs> C;
   C.valid = 0;
   C.fails = 0;
-  C.pause = 0;
+  C.pause = (A.tune & 1u) ? 0x7fffffffu : 0u;
   C.key[0] = C.key[1] = 0;
   hot_reset<Spec, 0>(C, true);
   hot_reset<Spec, 1>(C, true);
@@ -683,6 +683,264 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, spec_min_waves_per_simd<Spec>()) 
   dense_flush<Spec>(D, A.table, wave, n_waves, lane);
   hot_flush<Spec, 0>(C, A.table, lane, (C.valid & 1u) != 0);
   hot_flush<Spec, 1>(C, A.table, lane, (C.valid & 2u) != 0);
+  agg_flush(L, A.table, A.accs, Spec::n_accs);
+}
+
+
+// ------------------------------------------------- first pass of the high-cardinality mode
+// With very many groups the first pass keeps the frequent keys in the workgroup's LDS table and logs every other row
+// for the partition passes.  Per row that is a hash, a look at the table, and either a handful of LDS atomics or two
+// stores - but the general kernel above spends four times as many instructions as that on paths this mode never takes
+// (hot keys in registers, dense bins, a dominant key's wave reduction, the global table) and is bound by instruction
+// issue, not by LDS or HBM.  This kernel is the same plan with only what the mode needs:
+//  * the table is probed a pair of slots at a time (one 16-byte LDS read: buckets of two, two buckets), and a key
+//    that is not in the table when its probe meets an empty slot claims it (admission by second sighting, as above)
+//    or is logged - there is no third home;
+//  * with at most four accumulators the inputs are evaluated first and folded row by row, so that a row's LDS
+//    atomics sit under one test of its lane mask.
+struct SpillRows {
+  uint64_t key[VM_R];
+  uint32_t slot8[VM_R];  // byte offset (slot x 8) into the key array of rows whose group is in the LDS table
+  uint32_t hit;          // those rows
+  uint32_t miss;         // rows logged instead
+  uint64_t pos;          // log position of the lane's first logged row; the others follow
+};
+
+__device__ __forceinline__ void spill_lookup(const LdsTable &L, uint32_t active, SpillRows &G, SpillState &sp) {
+  const uint32_t mask = L.cap - 1;
+  uint32_t b[VM_R];
+  uint32_t open = active, hit = 0;
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    b[j] = hash32(G.key[j]) & mask & ~1u;
+    G.slot8[j] = 0;
+  }
+  {
+    // the one key equal to the empty marker lives in the reserved slot
+    uint32_t marker = 0;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) marker |= (((active >> j) & 1u) && G.key[j] == AGG_EMPTY_KEY) ? 1u << j : 0u;
+    if (__ballot(marker != 0) != 0) {
+      if (marker != 0) (void)atomicCAS(&L.keys[L.cap], AGG_EMPTY_KEY, 0ull);
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) G.slot8[j] = ((marker >> j) & 1u) ? L.cap * 8u : G.slot8[j];
+      hit |= marker;
+      open &= ~marker;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (r > 0 && __ballot(open != 0) == 0) break;
+    U64x2 two[VM_R];
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) {
+      two[j].x = two[j].y = 0;
+      if ((open >> j) & 1u) {
+        const volatile unsigned long long *q = &L.keys[b[j]];
+        two[j].x = q[0];
+        two[j].y = q[1];
+      }
+    }
+    uint32_t want = 0;  // rows whose probe ended at an empty slot without finding the key
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) {
+      const bool o = ((open >> j) & 1u) != 0;
+      const bool h0 = o && two[j].x == G.key[j], h1 = o && two[j].y == G.key[j];
+      const bool e0 = two[j].x == AGG_EMPTY_KEY, e1 = two[j].y == AGG_EMPTY_KEY;
+      const bool found = h0 || h1;
+      const bool ended = o && !found && (e0 || e1);
+      G.slot8[j] = found ? (b[j] + (h0 ? 0u : 1u)) * 8u : G.slot8[j];
+      hit |= found ? 1u << j : 0u;
+      want |= ended ? 1u << j : 0u;
+      b[j] = ended ? b[j] + (e0 ? 0u : 1u) : ((b[j] + 2u) & mask);  // the empty slot itself, or the next bucket
+      open &= (found || ended) ? ~(1u << j) : ~0u;
+    }
+    if (__ballot(want != 0) != 0) {
+      // (rare once the table has filled: claims happen while it fills and when a key is let in later)
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) {
+        bool got = false;
+        if ((want >> j) & 1u) {
+          bool admit = *(volatile uint32_t *)L.used < L.limit;
+          if (admit && L.door) {
+            const uint32_t hf = hash32(G.key[j]);
+            const uint32_t d = (hf >> 12) & (DOOR_ENTRIES - 1);
+            const uint16_t tag = (uint16_t)((hf >> 16) | 1u);
+            if (*(volatile uint16_t *)&L.door[d] != tag) {
+              L.door[d] = tag;
+              admit = false;
+            }
+          }
+          if (admit) {
+            const unsigned long long old = atomicCAS(&L.keys[b[j]], AGG_EMPTY_KEY, (unsigned long long)G.key[j]);
+            if (old == AGG_EMPTY_KEY) atomicAdd(L.used, 1u);
+            got = old == AGG_EMPTY_KEY || old == G.key[j];  // (lost to another key: the row is logged)
+          }
+        }
+        G.slot8[j] = got ? b[j] * 8u : G.slot8[j];
+        hit |= got ? 1u << j : 0u;
+      }
+    }
+  }
+  const uint32_t miss = active & ~hit;
+  G.hit = hit;
+  G.miss = miss;
+  G.pos = 0;
+  const uint64_t any = __ballot(miss != 0);
+  if (any != 0) {
+    // the rows without a slot go to the wave's log, in lane order
+    const uint32_t mine = (uint32_t)__popc(miss);
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int bit = 0; bit < 3; ++bit) {
+      const uint64_t m = __ballot(((mine >> bit) & 1u) != 0);
+      before += mbcnt64(m) << bit;
+      total += (uint32_t)__popcll(m) << bit;
+    }
+    G.pos = sp.base + sp.cursor + before;
+    uint32_t k = 0;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) {
+      if ((miss >> j) & 1u) sp.keys[G.pos + k] = G.key[j];
+      k += (miss >> j) & 1u;
+    }
+    sp.cursor += total;
+  }
+}
+
+// One evaluated input of row `J` into accumulator `ACC` of the row's slot.
+template <class Spec, int ACC, int J>
+__device__ __forceinline__ void spill_fold_one(const LdsTable &L, const Slot &in, const SpillRows &G) {
+  constexpr uint32_t op = Spec::acc_op[ACC], in_type = Spec::acc_type[ACC];
+  if (!((in.valid >> J) & 1u)) return;
+  uint64_t x = in.v[J];
+  unsigned long long *p = (unsigned long long *)((char *)(L.acc + (uint32_t)ACC * L.stride) + G.slot8[J]);
+  if constexpr (op == ACC_MIN || op == ACC_MAX) {
+    if (in_type == VT_F64 && u2d(x) != u2d(x)) return;  // NaN is ignored by min / max
+    x = ord_image(x, in_type);
+    if constexpr (op == ACC_MIN) atomicMin(p, (unsigned long long)x);
+    else atomicMax(p, (unsigned long long)x);
+  } else if constexpr (op == ACC_SUM_F64) {
+    atomicAdd((double *)p, u2d(x));
+  } else if constexpr (op == ACC_COUNT) {
+    atomicAdd(p, 1ull);
+  } else {
+    atomicAdd(p, (unsigned long long)x);
+  }
+  if constexpr (Spec::acc_track[ACC] != 0) atomicAdd((uint32_t *)((char *)(L.nn + (uint32_t)ACC * L.stride) + (G.slot8[J] >> 1)), 1u);
+}
+
+template <class Spec, int ACC, int J>
+__device__ __forceinline__ void spill_fold_row(const LdsTable &L, const Slot *in, const SpillRows &G) {
+  if constexpr (ACC < Spec::n_accs) {
+    spill_fold_one<Spec, ACC, J>(L, in[ACC], G);
+    spill_fold_row<Spec, ACC + 1, J>(L, in, G);
+  }
+}
+
+template <class Spec, int J>
+__device__ __forceinline__ void spill_fold_rows(const LdsTable &L, const Slot *in, const SpillRows &G) {
+  if constexpr (J < VM_R) {
+    if ((G.hit >> J) & 1u) {
+      atomicAdd((uint32_t *)((char *)L.rowcnt + (G.slot8[J] >> 1)), 1u);
+      spill_fold_row<Spec, 0, J>(L, in, G);
+    }
+    spill_fold_rows<Spec, J + 1>(L, in, G);
+  }
+}
+
+template <class Spec, int ACC, int J>
+__device__ __forceinline__ void spill_fold_acc(const LdsTable &L, const Slot &in, const SpillRows &G) {
+  if constexpr (J < VM_R) {
+    if ((G.hit >> J) & 1u) spill_fold_one<Spec, ACC, J>(L, in, G);
+    spill_fold_acc<Spec, ACC, J + 1>(L, in, G);
+  }
+}
+
+constexpr int SPILL_ROW_MAJOR_ACCS = 4;  // up to this many accumulators are folded row by row
+
+template <class Spec, int T>
+__device__ __forceinline__ void spill_tasks_static(const AggArgs &A, const LdsTable &L, RowCtx &c, const ColCache &K, SpillRows &G, Slot *in,
+                                                   SpillState &sp) {
+  if constexpr (T < Spec::n_tasks) {
+    constexpr uint32_t role = Spec::task_role[T], idx = Spec::task_idx[T];
+    Slot S[VM_MAX_DEPTH];
+    S[0].valid = 0xFu;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) S[0].v[j] = 1;
+    if constexpr (Spec::task_eval[T] != 0) eval_static<Spec, Spec::task_pc[T]>(A.prog, c, K, S);
+    if constexpr (role == ROLE_PRED) {
+      c.active &= S[0].valid & bool_bits(S[0]);
+      if (__ballot(c.active != 0) == 0) return;  // nothing of this wave-step survives the filter
+    } else if constexpr (role == ROLE_KEY) {
+      c.active &= S[0].valid;
+      constexpr uint32_t kbits = Spec::key_bits[idx], sh = Spec::key_shift[idx];
+      constexpr uint64_t fmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) G.key[j] |= (S[0].v[j] & fmask) << sh;
+    } else if constexpr (role == ROLE_LOOKUP) {
+      if (__ballot(c.active != 0) == 0) return;
+      spill_lookup(L, c.active, G, sp);
+      if constexpr (Spec::n_accs > SPILL_ROW_MAJOR_ACCS || Spec::n_accs == 0) {
+#pragma unroll
+        for (int j = 0; j < VM_R; ++j)
+          if ((G.hit >> j) & 1u) atomicAdd((uint32_t *)((char *)L.rowcnt + (G.slot8[j] >> 1)), 1u);
+      }
+    } else {
+      if (G.miss != 0 && A.spill_col[idx] != 0xffu) {
+        unsigned long long *dst = sp.vals + (uint64_t)A.spill_col[idx] * sp.capacity + G.pos;
+        uint32_t k = 0;
+#pragma unroll
+        for (int j = 0; j < VM_R; ++j) {
+          if ((G.miss >> j) & 1u) dst[k] = S[0].v[j];
+          k += (G.miss >> j) & 1u;
+        }
+      }
+      if constexpr (Spec::n_accs <= SPILL_ROW_MAJOR_ACCS) {
+        in[idx] = S[0];
+      } else {
+        if (__ballot(G.hit != 0) != 0) spill_fold_acc<Spec, (int)idx, 0>(L, S[0], G);
+      }
+    }
+    spill_tasks_static<Spec, T + 1>(A, L, c, K, G, in, sp);
+  } else {
+    if constexpr (Spec::n_accs <= SPILL_ROW_MAJOR_ACCS && Spec::n_accs > 0) {
+      if (__ballot(G.hit != 0) != 0) spill_fold_rows<Spec, 0>(L, in, G);
+    }
+  }
+}
+
+template <class Spec>
+__global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_spill_static(const AggArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lds_raw[];
+  const uint32_t lane = lane_id();
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t n_waves = blockDim.x >> 6;
+  const int64_t n = A.n_rows;
+  LdsTable L;
+  agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, Spec::n_accs, spec_tracks_validity<Spec>());
+  if (A.door_off != 0) L.door = (uint16_t *)((char *)lds_raw + A.door_off);
+  agg_lds_clear(L, A.accs, Spec::n_accs);  // ends with a barrier
+  SpillState sp = spill_begin(A.spill, wave);
+  const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
+  for (int64_t ws = (int64_t)blockIdx.x * n_waves + wave; ws < nsteps; ws += (int64_t)gridDim.x * n_waves) {
+    RowCtx c;
+    c.row0 = ws * VM_WAVE_ROWS;
+    c.n = n;
+    c.lane = lane;
+    c.active = in_range_bits(c.row0, lane, n);
+    ColCache K;
+    cache_fill_static<Spec, (1u << Spec::cache_n) - 1u, 0>(A.prog, c, K);
+    SpillRows G;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) G.key[j] = 0, G.slot8[j] = 0;
+    G.hit = 0;
+    G.miss = 0;
+    G.pos = 0;
+    Slot in[Spec::n_accs > 0 && Spec::n_accs <= SPILL_ROW_MAJOR_ACCS ? Spec::n_accs : 1];
+    spill_tasks_static<Spec, 0>(A, L, c, K, G, in, sp);
+  }
+  spill_end(A.spill, sp, wave, lane);
   agg_flush(L, A.table, A.accs, Spec::n_accs);
 }
 

@@ -3,6 +3,7 @@
 // (qe_lowering_describe) on a list of plans: no shape is written by hand, so a Spec can never
 // disagree with what the host would hand the interpreter for the same plan.
 #include <cstring>
+#include <string>
 
 #include "qe_kernels.h"
 #include "qe_signature.h"
@@ -19,6 +20,8 @@ struct Entry {
   void (*project)(const ProjectArgs &, int, hipStream_t);
   void (*filter)(const FilterArgs &, int, hipStream_t);
   void (*aggregate)(const AggArgs &, int, int, size_t, hipStream_t);
+  void (*aggregate_spill)(const AggArgs &, int, int, size_t, hipStream_t);  // the high-cardinality mode's first pass
+  const char *(*spill_name)();
 };
 
 template <class Spec>
@@ -48,13 +51,32 @@ void run_aggregate(const AggArgs &a, int grid, int block_threads, size_t lds, hi
   hipLaunchKernelGGL(qe_aggregate_static<Spec>, dim3(grid), dim3(block_threads), lds, s, a);
 }
 
-#define QE_ENTRY_PROJECT(S) Entry{S::name, S::sig, S::n_sig, run_project<S>, nullptr, nullptr},
-#define QE_ENTRY_FILTER(S) Entry{S::name, S::sig, S::n_sig, nullptr, run_filter<S>, nullptr},
-#define QE_ENTRY_AGGREGATE(S) Entry{S::name, S::sig, S::n_sig, nullptr, nullptr, run_aggregate<S>},
+template <class Spec>
+void run_aggregate_spill(const AggArgs &a, int grid, int block_threads, size_t lds, hipStream_t s) {
+  if (lds > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute((const void *)qe_aggregate_spill_static<Spec>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipGetLastError();
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(qe_aggregate_spill_static<Spec>, dim3(grid), dim3(block_threads), lds, s, a);
+}
+template <class Spec>
+const char *spill_kernel_name() {
+  // "qe_aggregate_static<shape>" -> "qe_aggregate_spill_static<shape>"
+  static const std::string name = std::string("qe_aggregate_spill") + (Spec::name + std::strlen("qe_aggregate"));
+  return name.c_str();
+}
+
+#define QE_ENTRY_PROJECT(S) Entry{S::name, S::sig, S::n_sig, run_project<S>, nullptr, nullptr, nullptr, nullptr},
+#define QE_ENTRY_FILTER(S) Entry{S::name, S::sig, S::n_sig, nullptr, run_filter<S>, nullptr, nullptr, nullptr},
+#define QE_ENTRY_AGGREGATE(S) Entry{S::name, S::sig, S::n_sig, nullptr, nullptr, run_aggregate<S>, run_aggregate_spill<S>, spill_kernel_name<S>},
 
 const Entry g_entries[] = {
     QE_STATIC_PROJECT_SPECS(QE_ENTRY_PROJECT) QE_STATIC_FILTER_SPECS(QE_ENTRY_FILTER)
-        QE_STATIC_AGGREGATE_SPECS(QE_ENTRY_AGGREGATE) Entry{nullptr, nullptr, 0, nullptr, nullptr, nullptr}};
+        QE_STATIC_AGGREGATE_SPECS(QE_ENTRY_AGGREGATE) Entry{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr}};
 
 const Entry *find(const std::vector<uint32_t> &sig) {
   for (const Entry *e = g_entries; e->name; ++e)
@@ -88,12 +110,13 @@ bool static_has_aggregate(const AggArgs &args) {
 }
 
 bool static_launch_aggregate(const AggArgs &args, int grid, int block_threads, size_t lds_bytes, hipStream_t stream, hipError_t *err,
-                             const char **kernel_name) {
+                             const char **kernel_name, bool spill_first_pass) {
   const Entry *e = find(signature(args));
   if (!e || !e->aggregate) return false;
-  e->aggregate(args, grid, block_threads, lds_bytes, stream);
+  if (spill_first_pass) e->aggregate_spill(args, grid, block_threads, lds_bytes, stream);
+  else e->aggregate(args, grid, block_threads, lds_bytes, stream);
   *err = hipGetLastError();
-  if (kernel_name) *kernel_name = e->name;
+  if (kernel_name) *kernel_name = spill_first_pass ? e->spill_name() : e->name;
   return true;
 }
 

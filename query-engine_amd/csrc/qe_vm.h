@@ -237,6 +237,8 @@ struct AggArgs {
   uint8_t spill_col[VM_MAX_ACCS];  // value column an accumulator's input is logged to; 0xff: not this one
   uint32_t block_threads;          // host only: threads per workgroup of the launch (0 = VM_BLOCK_THREADS)
   uint32_t door_off;               // byte offset of the admission tags in dynamic LDS (high-cardinality mode); 0 = none
+  uint32_t tune;                   // bit 0: no hot keys in registers for this launch; bit 1 (host): the caller promised many groups
+  uint32_t tune_pad;
 };
 
 // Does the workgroup's LDS table keep per-accumulator counts of valid inputs?  Host and device size the table alike.
