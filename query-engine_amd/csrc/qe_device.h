@@ -1038,6 +1038,100 @@ __device__ __forceinline__ void lds_find_or_claim4(const LdsTable &L, const uint
   }
 }
 
+// The same lookup, a pair of slots at a time: a key's probe sequence is the aligned pairs (buckets) from the one its
+// hash names onwards, each read with one 16-byte LDS load, and a key that meets an empty slot before itself claims the
+// bucket's first empty slot.  `rounds` buckets are looked at; rows whose key was neither found nor placed by then - or
+// that lost a claim to another key, or were not admitted - are simply not in the returned mask (the caller has another
+// home for them).  slot8[j] = byte offset of row j's slot in an array of 8-byte entries (slot x 8).
+// ADMISSION: claims obey the table's limit and, when it has one, the second-sighting filter (lds_find_or_claim4).
+template <bool ADMISSION>
+__device__ __forceinline__ uint32_t lds_pair_find_or_claim4(const LdsTable &L, const uint64_t (&key)[VM_R], uint32_t rows, int rounds,
+                                                            uint32_t (&slot8)[VM_R]) {
+  const uint32_t mask = L.cap - 1;
+  uint32_t b[VM_R];
+  uint32_t open = rows, hit = 0;
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    b[j] = hash32(key[j]) & mask & ~1u;
+    slot8[j] = 0;
+  }
+  {
+    // the one key equal to the empty marker lives in the reserved slot
+    uint32_t marker = 0;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) marker |= (((rows >> j) & 1u) && key[j] == AGG_EMPTY_KEY) ? 1u << j : 0u;
+    if (__ballot(marker != 0) != 0) {
+      if (marker != 0) (void)atomicCAS(&L.keys[L.cap], AGG_EMPTY_KEY, 0ull);
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) slot8[j] = ((marker >> j) & 1u) ? L.cap * 8u : slot8[j];
+      hit |= marker;
+      open &= ~marker;
+    }
+  }
+#pragma unroll 1
+  for (int r = 0; r < rounds; ++r) {
+    if (__ballot(open != 0) == 0) break;
+    uint64_t k0[VM_R], k1[VM_R];
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) {
+      k0[j] = k1[j] = 0;
+      if ((open >> j) & 1u) {
+        // (b is even and the key array 16-byte aligned: one 16-byte read)
+        const U64x2 two = *(const U64x2 *)__builtin_assume_aligned(&L.keys[b[j]], 16);
+        k0[j] = two.x;
+        k1[j] = two.y;
+      }
+    }
+    uint32_t want = 0;  // rows whose probe ended at an empty slot without finding the key
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) {
+      const bool o = ((open >> j) & 1u) != 0;
+      const bool h0 = o && k0[j] == key[j], h1 = o && k1[j] == key[j];
+      const bool e0 = k0[j] == AGG_EMPTY_KEY, e1 = k1[j] == AGG_EMPTY_KEY;
+      const bool found = h0 || h1;
+      const bool ended = o && !found && (e0 || e1);
+      slot8[j] = found ? (b[j] + (h0 ? 0u : 1u)) * 8u : slot8[j];
+      hit |= found ? 1u << j : 0u;
+      want |= ended ? 1u << j : 0u;
+      b[j] = ended ? b[j] + (e0 ? 0u : 1u) : ((b[j] + 2u) & mask);  // the empty slot itself, or the next bucket
+      open &= (found || ended) ? ~(1u << j) : ~0u;
+    }
+    if (__ballot(want != 0) != 0) {
+      // (rare once the table has filled: claims happen while it fills and when a key is let in later)
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) {
+        bool got = false, again = false;
+        if ((want >> j) & 1u) {
+          bool admit = *(volatile uint32_t *)L.used < L.limit;
+          if (ADMISSION && admit && L.door) {
+            const uint32_t hf = hash32(key[j]);
+            const uint32_t d = (hf >> 12) & (DOOR_ENTRIES - 1);
+            const uint16_t tag = (uint16_t)((hf >> 16) | 1u);
+            if (*(volatile uint16_t *)&L.door[d] != tag) {
+              L.door[d] = tag;
+              admit = false;
+            }
+          }
+          if (admit) {
+            const unsigned long long old = atomicCAS(&L.keys[b[j]], AGG_EMPTY_KEY, (unsigned long long)key[j]);
+            if (old == AGG_EMPTY_KEY) atomicAdd(L.used, 1u);
+            got = old == AGG_EMPTY_KEY || old == key[j];
+            again = !got;  // lost the slot to another key: look at this bucket again (its other slot may be free)
+          }
+        }
+        slot8[j] = got ? b[j] * 8u : slot8[j];
+        hit |= got ? 1u << j : 0u;
+        if (!ADMISSION) {
+          // every key must find a home here: the row goes on probing from its bucket
+          open |= again ? 1u << j : 0u;
+          b[j] = again ? (b[j] & ~1u) : b[j];
+        }
+      }
+    }
+  }
+  return hit;
+}
+
 __device__ __forceinline__ void acc_apply(unsigned long long *p, uint32_t op, uint64_t v) {
   switch (op) {
     case ACC_SUM_F64: atomicAdd((double *)p, u2d(v)); break;

@@ -752,8 +752,9 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
           break;
         }
         need_numeric();
-        int a = fix_scales ? add_fix_sum(spec, make_to_f64(e), (*fix_scales)[i], false)
-                           : add_acc(spec, ACC_SUM_F64, QE_TYPE_FLOAT64, false, make_to_f64(e));
+        // (a Float64 input needs no cast: AVG(x) then shares SUM(x)'s accumulator)
+        const ExprPtr as_f64 = t == QE_TYPE_FLOAT64 ? e : make_to_f64(e);
+        int a = fix_scales ? add_fix_sum(spec, as_f64, (*fix_scales)[i], false) : add_acc(spec, ACC_SUM_F64, QE_TYPE_FLOAT64, false, as_f64);
         int b = -1;
         uint8_t src = CNT_ROWS;
         if (nullable) {
@@ -939,6 +940,8 @@ static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &
   QE_HIP(hipMemcpyAsync(ctx->host_counters + 2, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   ctx->sync();
   const int64_t m = (int64_t)ctx->host_counters[2];
+  static const bool verbose = getenv("QE_SPILL_VERBOSE") != nullptr;
+  if (verbose) fprintf(stderr, "qe_gpu: high-cardinality mode: %lld of %lld rows logged, %d partitions\n", (long long)m, (long long)args.n_rows, 1 << bits);
   if (m == 0) return;
   const uint64_t stride = ((uint64_t)m + 63) & ~63ull;  // rows between the value columns of a partitioned copy
   const uint32_t n_in = args.spill.n_inputs;
