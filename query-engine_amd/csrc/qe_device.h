@@ -881,11 +881,19 @@ struct LdsTable {
   uint32_t limit;
 };
 
-__device__ __forceinline__ int64_t global_find_or_claim(const AggTable &T, uint64_t key, uint64_t h) {
+// COUNT_HERE: a claimed slot is counted into the table's group counter on the spot.  Callers that claim many slots at
+// once (a workgroup flushing its LDS table) pass false, take `claimed` and add the wave's total with one atomic: a
+// million claims are otherwise a million atomics on one word.
+template <bool COUNT_HERE = true>
+__device__ __forceinline__ int64_t global_find_or_claim(const AggTable &T, uint64_t key, uint64_t h, bool *claimed = nullptr) {
+  if (claimed) *claimed = false;
   if (key == AGG_EMPTY_KEY) {
     // the one key that collides with the empty marker lives in the reserved slot
     unsigned long long old = atomicCAS(&T.keys[T.cap], AGG_EMPTY_KEY, 0ull);
-    if (old == AGG_EMPTY_KEY) atomicAdd(&T.ctrl[0], 1ull);
+    if (old == AGG_EMPTY_KEY) {
+      if (COUNT_HERE) atomicAdd(&T.ctrl[0], 1ull);
+      else if (claimed) *claimed = true;
+    }
     return (int64_t)T.cap;
   }
   uint64_t mask = T.cap - 1;
@@ -897,7 +905,8 @@ __device__ __forceinline__ int64_t global_find_or_claim(const AggTable &T, uint6
     if (cur == AGG_EMPTY_KEY) {
       unsigned long long old = atomicCAS(&T.keys[s], AGG_EMPTY_KEY, (unsigned long long)key);
       if (old == AGG_EMPTY_KEY) {
-        atomicAdd(&T.ctrl[0], 1ull);
+        if (COUNT_HERE) atomicAdd(&T.ctrl[0], 1ull);
+        else if (claimed) *claimed = true;
         return (int64_t)s;
       }
       if (old == key) return (int64_t)s;
@@ -1415,26 +1424,40 @@ __device__ __forceinline__ void agg_fold(const LdsTable &L, const AggTable &T, u
   }
 }
 
-// Workgroup's LDS table -> global table, once, at the end of the kernel.
+// Workgroup's LDS table -> global table, once, at the end of the kernel.  Every wave walks its slots in step (the
+// loop's trip count is the same for all lanes) so that the slots the wave claims in the global table are counted with
+// one atomic; min / max go out as atomics straight away (a read first would be a dependent trip to HBM per group).
 __device__ __forceinline__ void agg_flush(const LdsTable &L, const AggTable &T, const VmAcc *accs, int n_accs) {
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < L.stride; i += blockDim.x) {
-    unsigned long long k = L.keys[i];
-    uint32_t rc = L.rowcnt[i];
-    if (i == L.cap) {
-      if (k == AGG_EMPTY_KEY) continue;  // reserved slot never claimed
+  const uint32_t rounds = (L.stride + blockDim.x - 1) / blockDim.x;
+  for (uint32_t r = 0; r < rounds; ++r) {
+    const uint32_t i = r * blockDim.x + threadIdx.x;
+    bool live = i < L.stride;
+    unsigned long long k = live ? L.keys[i] : AGG_EMPTY_KEY;
+    if (live && i == L.cap) {
+      live = k != AGG_EMPTY_KEY;  // reserved slot: claimed or not
       k = AGG_EMPTY_KEY;
     } else if (k == AGG_EMPTY_KEY) {
-      continue;
+      live = false;
     }
-    int64_t g = global_find_or_claim(T, k, mix64(k));
+    bool claimed = false;
+    int64_t g = -1;
+    if (live) g = global_find_or_claim<false>(T, k, mix64(k), &claimed);
+    const uint64_t fresh = __ballot(claimed);
+    if (fresh != 0 && lane_id() == (uint32_t)__builtin_ctzll(fresh)) atomicAdd(&T.ctrl[0], (unsigned long long)__popcll(fresh));
     if (g < 0) continue;
+    const uint32_t rc = L.rowcnt[i];
     if (rc) atomicAdd(&T.rowcnt[g], (unsigned long long)rc);
     for (int a = 0; a < n_accs; ++a) {
-      uint32_t op = accs[a].op;
-      unsigned long long val = L.acc[a * L.stride + i];
-      if (val != acc_identity(op) || op == ACC_SUM_F64) acc_apply(&T.acc[(uint64_t)a * T.stride + g], op, val);
-      uint32_t nn = L.nn ? L.nn[a * L.stride + i] : 0u;
+      const uint32_t op = accs[a].op;
+      const unsigned long long val = L.acc[a * L.stride + i];
+      unsigned long long *dst = &T.acc[(uint64_t)a * T.stride + g];
+      if (val != acc_identity(op) || op == ACC_SUM_F64) {
+        if (op == ACC_MIN) atomicMin(dst, val);
+        else if (op == ACC_MAX) atomicMax(dst, val);
+        else acc_apply(dst, op, val);
+      }
+      const uint32_t nn = L.nn ? L.nn[a * L.stride + i] : 0u;
       if (nn) atomicAdd(&T.nn[(uint64_t)a * T.stride + g], (unsigned long long)nn);
     }
   }

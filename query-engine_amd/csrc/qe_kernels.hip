@@ -537,8 +537,14 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
       // general path below, which looks the rows up again (a lookup changes nothing but the table's key slots).
       if (r0 + VM_WAVE_ROWS <= end) {
         int32_t slot[VM_R];
-        lds_find_or_claim4(L, G.key, 0xFu, LDS_MAX_PROBE, slot);
+        if (A.ablate & 4) {
+#pragma unroll
+          for (int j = 0; j < VM_R; ++j) slot[j] = (int32_t)(hash32(G.key[j]) & (L.cap - 1));
+        } else {
+          lds_find_or_claim4(L, G.key, 0xFu, LDS_MAX_PROBE, slot);
+        }
         if (__ballot((slot[0] | slot[1] | slot[2] | slot[3]) < 0) == 0) {
+          if (A.ablate & 2) continue;
 #pragma unroll
           for (int j = 0; j < VM_R; ++j) atomicAdd(&L.rowcnt[slot[j]], 1u);
 #pragma unroll 1
@@ -553,10 +559,14 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
               const uint32_t op = A.accs[a].op, in_type = A.accs[a].in_type;
               unsigned long long *acc = L.acc + (size_t)a * L.stride;
               if (op == ACC_MIN || op == ACC_MAX) {
+                // (the atomic straight away: a read first, to skip atomics that cannot win, is a dependent LDS round trip per row)
 #pragma unroll
                 for (int j = 0; j < VM_R; ++j) {
                   const bool nan = in_type == VT_F64 && u2d(in.v[j]) != u2d(in.v[j]);  // NaN is ignored by min / max
-                  if (!nan) acc_apply(acc + slot[j], op, ord_image(in.v[j], in_type));
+                  if (!nan) {
+                    if (op == ACC_MIN) atomicMin(acc + slot[j], (unsigned long long)ord_image(in.v[j], in_type));
+                    else atomicMax(acc + slot[j], (unsigned long long)ord_image(in.v[j], in_type));
+                  }
                 }
               } else {
 #pragma unroll
@@ -585,7 +595,7 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
           if (A.acc_col[a] == v) agg_fold(L, A.table, a, A.accs[a].op, A.accs[a].in_type, false, in, G, lane);
       }
     }
-    agg_flush(L, A.table, A.accs, A.n_accs);  // starts with a barrier
+    if (!(A.ablate & 1)) agg_flush(L, A.table, A.accs, A.n_accs);  // starts with a barrier
   }
 }
 
@@ -1285,7 +1295,10 @@ hipError_t launch_aggregate_partitioned(const PartArgs &args, const DeviceInfo &
     attr_set = true;
   }
   int grid = args.n_parts < dev.cus ? args.n_parts : dev.cus;
-  hipLaunchKernelGGL(qe_aggregate_partitioned_kernel, dim3(grid), dim3(PART_THREADS), lds, stream, args);
+  static int ablate = tuned("QE_PART_ABLATE", 0);
+  PartArgs a2 = args;
+  a2.ablate = ablate;
+  hipLaunchKernelGGL(qe_aggregate_partitioned_kernel, dim3(grid), dim3(PART_THREADS), lds, stream, a2);
   return hipGetLastError();
 }
 

@@ -265,6 +265,8 @@ struct PartArgs {
   uint32_t lds_cap;
   uint32_t lds_limit;
   unsigned long long *ticket;      // zeroed before the launch
+  int32_t ablate;                  // timing experiments only (QE_PART_ABLATE): 1 no flush, 2 no fold, 4 no lookup
+  int32_t ablate_pad;
 };
 
 constexpr int FIX_FRACTION_BITS = 96;  // fixed-point digits below 2^S
