@@ -1427,6 +1427,10 @@ __device__ __forceinline__ void agg_fold(const LdsTable &L, const AggTable &T, u
 // Workgroup's LDS table -> global table, once, at the end of the kernel.  Every wave walks its slots in step (the
 // loop's trip count is the same for all lanes) so that the slots the wave claims in the global table are counted with
 // one atomic; min / max go out as atomics straight away (a read first would be a dependent trip to HBM per group).
+// EXCLUSIVE: no other workgroup of the launch holds any of this table's keys (the partition-wise aggregate: partitions
+// share no key) - a group's row in the global table is then read, combined and stored plainly, and a group claimed
+// just now is only stored; slots are still claimed by compare-and-swap (keys of different partitions meet in the table).
+template <bool EXCLUSIVE = false>
 __device__ __forceinline__ void agg_flush(const LdsTable &L, const AggTable &T, const VmAcc *accs, int n_accs) {
   __syncthreads();
   const uint32_t rounds = (L.stride + blockDim.x - 1) / blockDim.x;
@@ -1447,6 +1451,19 @@ __device__ __forceinline__ void agg_flush(const LdsTable &L, const AggTable &T, 
     if (fresh != 0 && lane_id() == (uint32_t)__builtin_ctzll(fresh)) atomicAdd(&T.ctrl[0], (unsigned long long)__popcll(fresh));
     if (g < 0) continue;
     const uint32_t rc = L.rowcnt[i];
+    if (EXCLUSIVE) {
+      T.rowcnt[g] = (claimed ? 0ull : T.rowcnt[g]) + rc;
+      for (int a = 0; a < n_accs; ++a) {
+        const uint32_t op = accs[a].op;
+        unsigned long long *dst = &T.acc[(uint64_t)a * T.stride + g];
+        *dst = acc_combine(op, claimed ? acc_identity(op) : *dst, L.acc[a * L.stride + i]);
+        if (L.nn) {
+          unsigned long long *dn = &T.nn[(uint64_t)a * T.stride + g];
+          *dn = (claimed ? 0ull : *dn) + L.nn[a * L.stride + i];
+        }
+      }
+      continue;
+    }
     if (rc) atomicAdd(&T.rowcnt[g], (unsigned long long)rc);
     for (int a = 0; a < n_accs; ++a) {
       const uint32_t op = accs[a].op;

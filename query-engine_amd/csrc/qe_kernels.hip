@@ -595,7 +595,7 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
           if (A.acc_col[a] == v) agg_fold(L, A.table, a, A.accs[a].op, A.accs[a].in_type, false, in, G, lane);
       }
     }
-    if (!(A.ablate & 1)) agg_flush(L, A.table, A.accs, A.n_accs);  // starts with a barrier
+    if (!(A.ablate & 1)) agg_flush<true>(L, A.table, A.accs, A.n_accs);  // starts with a barrier
   }
 }
 
@@ -1187,6 +1187,8 @@ hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipSt
     // registers take a dominant key off the LDS atomics.
     static int lean = tuned("QE_AGGREGATE_SPILL_KERNEL", 1);
     const bool many_groups = args.spill.keys != nullptr && (args.tune & 2u) != 0;
+    static int no_flush = tuned("QE_SPILL_ABLATE_FLUSH", 0);
+    if (no_flush) args.tune |= 4u;
     const bool spill_kernel = lean != 2 && many_groups;
     if (many_groups && !spill_kernel) args.tune |= 1u;  // (with many groups the hot keys cost more than they save: 2.67 -> 2.42 ms per 256 M rows)
     if (static_launch_aggregate(args, grid, AGG_WIDE_THREADS, lds, stream, &werr, kernel_name, spill_kernel)) return werr;

@@ -869,7 +869,7 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_spill_static
     spill_tasks_static<Spec, 0>(A, L, c, K, G, in, sp);
   }
   spill_end(A.spill, sp, wave, lane);
-  agg_flush(L, A.table, A.accs, Spec::n_accs);
+  if (!(A.tune & 4u)) agg_flush(L, A.table, A.accs, Spec::n_accs);  // (bit 2: timing experiments)
 }
 
 }  // namespace qe
