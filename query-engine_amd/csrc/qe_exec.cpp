@@ -833,7 +833,25 @@ struct SpillPlan {
   BufferPtr keys, vals, counts;
   int waves = 0;
   uint8_t acc_col[VM_MAX_ACCS];
+  // the partition passes: hash bits that name a partition, workgroups, the cell tables [partition][workgroup]
+  int bits = 0, blocks = 0;
+  BufferPtr cell_buf, cell1_buf, scan_buf;
+  bool counted = false;  // the first pass filled the cell table and the log's length itself
 };
+
+// Partitions of the second phase: as few as keep a partition's distinct keys within 5/8 of its LDS table.
+static int spill_partition_bits(int n_accs, int64_t group_hint) {
+  const int64_t keys_per_partition = (int64_t)partitioned_lds_slots(n_accs) * 5 / 8;
+  // (and no fewer than 256: a partition is one workgroup's work, and every compute unit should have some)
+  int bits = 8;
+  while (bits < 11 && ((int64_t)1 << bits) * keys_per_partition < group_hint) ++bits;
+  static int forced_bits = [] {
+    const char *e = getenv("QE_SPILL_BITS");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced_bits >= 1 && forced_bits <= 11 && forced_bits >= bits) bits = forced_bits;
+  return bits;
+}
 
 static bool spill_enabled() {
   static int v = [] {
@@ -900,38 +918,49 @@ static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &b
   a.keys = (unsigned long long *)sp.keys->ptr;
   a.vals = (unsigned long long *)sp.vals->ptr;
   a.counts = (uint32_t *)sp.counts->ptr;
+  // the partition passes' geometry and tables, now: a first pass that can counts its logged rows per partition itself
+  static int forced_blocks = [] {
+    const char *e = getenv("QE_SPILL_BLOCKS");
+    return e ? atoi(e) : 0;
+  }();
+  sp.bits = spill_partition_bits(args.n_accs, group_hint);
+  sp.blocks = forced_blocks > 0 ? forced_blocks : ctx->dev.cus;
+  const size_t cells = spill_cells(sp.bits, sp.blocks), cells1 = spill_cells(spill_level1_bits(sp.bits), sp.blocks);
+  sp.cell_buf = device_buffer(ctx, (cells + 1) * 4 + 64);
+  sp.cell1_buf = device_buffer(ctx, (cells1 + 1) * 4 + 64);
+  sp.scan_buf = device_buffer(ctx, scan_scratch_elems((int64_t)cells) * 4 + 64);
+  QE_HIP(hipMemsetAsync(ctx->counters + 2, 0, 2 * sizeof(unsigned long long), ctx->stream));  // log length, partition ticket
+  static const int fuse_count = [] {
+    const char *e = getenv("QE_SPILL_FUSED_COUNT");  // 0: off; 2 (timing experiments): the segment runs without the fused count
+    return e ? atoi(e) : 1;
+  }();
+  if (fuse_count && args.block_threads == (uint32_t)AGG_WIDE_THREADS && grid == sp.blocks) {
+    // one first-pass workgroup per column of the cell table: workgroup b's waves own segments [16 b, 16 b + 16)
+    a.seg_chunk = AGG_WIDE_THREADS / 64;
+    if (fuse_count != 2) {
+      args.cells = (int32_t *)sp.cell_buf->ptr;
+      args.cells_total = ctx->counters + 2;
+      args.cell_bits = sp.bits;
+    }
+  }
   sp.on = true;
   return sp;
 }
 
 // Second phase: partition the log by key hash (count, scan, one or two scatter passes), aggregate partition by partition.
 static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &args, int64_t group_hint) {
-  // partitions: as few as keep a partition's distinct keys within 5/8 of the LDS table of the second phase
-  const int64_t keys_per_partition = (int64_t)partitioned_lds_slots(args.n_accs) * 5 / 8;
-  // (and no fewer than 256: a partition is one workgroup's work, and every compute unit should have some)
-  int bits = 8;
-  while (bits < 11 && ((int64_t)1 << bits) * keys_per_partition < group_hint) ++bits;
-  static int forced_bits = [] {
-    const char *e = getenv("QE_SPILL_BITS");
-    return e ? atoi(e) : 0;
-  }();
-  if (forced_bits >= 1 && forced_bits <= 11 && forced_bits >= bits) bits = forced_bits;
-  static int forced_blocks = [] {
-    const char *e = getenv("QE_SPILL_BLOCKS");
-    return e ? atoi(e) : 0;
-  }();
-  const int blocks = forced_blocks > 0 ? forced_blocks : ctx->dev.cus;
+  (void)group_hint;
+  const int bits = sp.bits, blocks = sp.blocks;
   const int bits1 = spill_level1_bits(bits);
   const size_t cells = spill_cells(bits, blocks), cells1 = spill_cells(bits1, blocks);
-  BufferPtr cell_buf = device_buffer(ctx, (cells + 1) * 4 + 64);
-  BufferPtr cell1_buf = device_buffer(ctx, (cells1 + 1) * 4 + 64);
-  BufferPtr scan_buf = device_buffer(ctx, scan_scratch_elems((int64_t)cells) * 4 + 64);
-  int32_t *cell = (int32_t *)cell_buf->ptr, *cell1 = (int32_t *)cell1_buf->ptr;
-  unsigned long long *total = ctx->counters + 2;
-  QE_HIP(hipMemsetAsync(total, 0, 2 * sizeof(unsigned long long), ctx->stream));
-  ctx->prof_begin("qe_spill_count_kernel");
-  QE_HIP(launch_spill_count(args.spill, sp.waves, bits, blocks, cell, total, ctx->stream));
-  ctx->prof_end();
+  const BufferPtr &scan_buf = sp.scan_buf;
+  int32_t *cell = (int32_t *)sp.cell_buf->ptr, *cell1 = (int32_t *)sp.cell1_buf->ptr;
+  unsigned long long *total = ctx->counters + 2;  // (zeroed before the first pass, with the partition ticket behind it)
+  if (!sp.counted) {
+    ctx->prof_begin("qe_spill_count_kernel");
+    QE_HIP(launch_spill_count(args.spill, sp.waves, bits, blocks, cell, total, ctx->stream));
+    ctx->prof_end();
+  }
   if (bits1 < bits) {
     QE_HIP(launch_spill_cells_level1(cell, cell1, bits, blocks, ctx->stream));
     QE_HIP(launch_exclusive_scan_i32(cell1, (int64_t)cells1, (int32_t *)scan_buf->ptr, ctx->stream));
@@ -1270,7 +1299,7 @@ struct AggState {
     SpillPlan sp = plan_spill(ctx, schema, bspec, args, effective_hint());
     const char *kname = "qe_aggregate_kernel";
     ctx->prof_begin(kname, in.rows);
-    QE_HIP(launch_aggregate(args, ctx->dev, ctx->stream, &kname));
+    QE_HIP(launch_aggregate(args, ctx->dev, ctx->stream, &kname, &sp.counted));
     ctx->prof_end(kname);
     if (sp.on) aggregate_spilled(ctx, sp, args, effective_hint());
     if (!comp.keepalive.empty()) ctx->sync();

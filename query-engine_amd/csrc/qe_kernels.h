@@ -28,7 +28,8 @@ size_t filter_scratch_bytes(int64_t n_rows);
 int64_t filter_num_tiles(int64_t n_rows);
 
 // Hash aggregate update over one batch.
-hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name = nullptr);
+// `counted` (may be null): whether the launch filled args.cells / args.cells_total (AggArgs::cells).
+hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name = nullptr, bool *counted = nullptr);
 // Slots of the workgroup's LDS table (`wide`: for the 1024-thread launch geometry, see AggArgs::block_threads).
 uint32_t aggregate_lds_slots(const AggArgs &args, const DeviceInfo &dev, int64_t group_hint, bool wide);
 // Whether a kernel that can be launched wide exists for this shape right now.

@@ -247,7 +247,10 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_count_kernel(AggSpill s
   for (int p = threadIdx.x; p < P; p += blockDim.x) s_cell[p] = 0u;
   __syncthreads();
   unsigned long long mine = 0;
-  for (int seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
+  const int seg0 = sp.seg_chunk ? (int)(blockIdx.x * sp.seg_chunk) : (int)blockIdx.x;
+  const int seg_end = sp.seg_chunk ? min(n_segments, seg0 + (int)sp.seg_chunk) : n_segments;
+  const int seg_step = sp.seg_chunk ? 1 : (int)gridDim.x;
+  for (int seg = seg0; seg < seg_end; seg += seg_step) {
     const uint32_t cnt = sp.counts[seg];
     const uint64_t base = (uint64_t)seg * sp.rows_per_wave;
     for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) atomicAdd(&s_cell[partition_of(sp.keys[base + i], bits)], 1u);
@@ -349,12 +352,17 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_kernel(const Sc
   const unsigned long long *src_vals = A.level == 1 ? A.sp.vals : A.src_vals;
   const uint64_t src_stride = A.level == 1 ? A.sp.capacity : A.src_stride;
   const int64_t n_cells = (int64_t)A.parts1 * gridDim.x;
+  // level 1: this workgroup's segments - every gridDim.x-th, or a run of seg_chunk (AggSpill::seg_chunk)
+  const int seg_step = A.level == 1 ? (A.sp.seg_chunk ? 1 : (int)gridDim.x) : 1;
+  const int seg_end = A.level == 1 ? (A.sp.seg_chunk ? (int)((blockIdx.x + 1) * A.sp.seg_chunk) : A.n_segments) : A.parts1;
   auto open_segment = [&](Round &r) {  // r.seg names a candidate: skips empty segments, invalid when none is left
     for (;;) {
       if (A.level == 1) {
-        if (r.seg >= A.n_segments) break;
-        r.cnt = A.sp.counts[r.seg];
-        r.first = (uint64_t)r.seg * A.sp.rows_per_wave;
+        if (r.seg >= seg_end) break;
+        const int seg = r.seg;
+        if (seg >= A.n_segments) break;
+        r.cnt = A.sp.counts[seg];
+        r.first = (uint64_t)seg * A.sp.rows_per_wave;
       } else {
         if (r.seg >= A.parts1) break;
         const int64_t cell = (int64_t)r.seg * gridDim.x + blockIdx.x;
@@ -368,14 +376,14 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_kernel(const Sc
         r.valid = true;
         return;
       }
-      r.seg += A.level == 1 ? (int)gridDim.x : 1;
+      r.seg += seg_step;
     }
     r.valid = false;
   };
   auto advance = [&](Round &r) {
     r.i0 += blockDim.x * (uint32_t)SCATTER_ROWS;
     if (r.i0 >= r.cnt) {
-      r.seg += A.level == 1 ? (int)gridDim.x : 1;
+      r.seg += seg_step;
       open_segment(r);
     }
   };
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_kernel(const Sc
   }
   BAR();
   Round cur;
-  cur.seg = A.level == 1 ? (int)blockIdx.x : 0;
+  cur.seg = A.level == 1 ? (A.sp.seg_chunk ? (int)(blockIdx.x * A.sp.seg_chunk) : (int)blockIdx.x) : 0;
   cur.first = 0;
   cur.cnt = 0;
   cur.i0 = 0;
@@ -1167,7 +1175,8 @@ static bool dense_bins_wanted(const AggArgs &args, size_t lds, int grid, const D
   return total <= 64 * 1024 && (size_t)per_cu * (total + 512) <= (size_t)144 * 1024;
 }
 
-hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name) {
+hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name, bool *counted) {
+  if (counted) *counted = false;
   if (args_in.n_rows <= 0) return hipSuccess;
   AggArgs args = args_in;
   size_t lds = agg_lds_bytes(args.n_accs, args.lds_cap, agg_tracks_validity(args.accs, args.n_accs));
@@ -1191,6 +1200,18 @@ hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipSt
     if (no_flush) args.tune |= 4u;
     const bool spill_kernel = lean != 2 && many_groups;
     if (many_groups && !spill_kernel) args.tune |= 1u;  // (with many groups the hot keys cost more than they save: 2.67 -> 2.42 ms per 256 M rows)
+    // the first pass counts its logged rows per partition when the caller asked for it (args.cells), the launch has one
+    // workgroup per column of the cell table, and the histogram fits next to the table
+    const size_t hist_at = (lds + 15) & ~(size_t)15;
+    const bool counts = spill_kernel && args.cells != nullptr && args.spill.seg_chunk == (uint32_t)(AGG_WIDE_THREADS / 64) &&
+                        hist_at + ((size_t)4 << args.cell_bits) <= (size_t)160 * 1024;
+    if (counts) {
+      args.hist_off = (uint32_t)hist_at;
+      lds = hist_at + ((size_t)4 << args.cell_bits);
+    } else {
+      args.cells = nullptr;
+    }
+    if (counted) *counted = counts;
     if (static_launch_aggregate(args, grid, AGG_WIDE_THREADS, lds, stream, &werr, kernel_name, spill_kernel)) return werr;
     if (spill_kernel) {
       if (jit_launch(JIT_AGGREGATE_SPILL, spec_fields_spill(args), &args, dev.jit, dev.device, grid, AGG_WIDE_THREADS, lds, stream, &werr, kernel_name)) return werr;
@@ -1199,6 +1220,7 @@ hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipSt
     }
     return hipErrorInvalidConfiguration;
   }
+  args.cells = nullptr;
   if (dev.specialised && dense_bins_wanted(args, lds, grid, dev)) {
     args.dense_off = (int32_t)((lds + 15) & ~(size_t)15);
     lds = (size_t)args.dense_off + dense_bins_bytes(args.n_accs);

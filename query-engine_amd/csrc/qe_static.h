@@ -706,7 +706,7 @@ struct SpillRows {
   uint64_t pos;          // log position of the lane's first logged row; the others follow
 };
 
-__device__ __forceinline__ void spill_lookup(const LdsTable &L, uint32_t active, SpillRows &G, SpillState &sp) {
+__device__ __forceinline__ void spill_lookup(const LdsTable &L, uint32_t active, SpillRows &G, SpillState &sp, uint32_t *hist, int hist_bits) {
   const uint32_t hit = lds_pair_find_or_claim4<true>(L, G.key, active, 2, G.slot8);
   const uint32_t miss = active & ~hit;
   G.hit = hit;
@@ -727,7 +727,10 @@ __device__ __forceinline__ void spill_lookup(const LdsTable &L, uint32_t active,
     uint32_t k = 0;
 #pragma unroll
     for (int j = 0; j < VM_R; ++j) {
-      if ((miss >> j) & 1u) sp.keys[G.pos + k] = G.key[j];
+      if ((miss >> j) & 1u) {
+        sp.keys[G.pos + k] = G.key[j];
+        if (hist) atomicAdd(&hist[hash32(G.key[j]) >> (32 - hist_bits)], 1u);  // (= partition_of: what the partition passes go by)
+      }
       k += (miss >> j) & 1u;
     }
     sp.cursor += total;
@@ -789,7 +792,7 @@ constexpr int SPILL_ROW_MAJOR_ACCS = 4;  // up to this many accumulators are fol
 
 template <class Spec, int T>
 __device__ __forceinline__ void spill_tasks_static(const AggArgs &A, const LdsTable &L, RowCtx &c, const ColCache &K, SpillRows &G, Slot *in,
-                                                   SpillState &sp) {
+                                                   SpillState &sp, uint32_t *hist) {
   if constexpr (T < Spec::n_tasks) {
     constexpr uint32_t role = Spec::task_role[T], idx = Spec::task_idx[T];
     Slot S[VM_MAX_DEPTH];
@@ -808,7 +811,7 @@ __device__ __forceinline__ void spill_tasks_static(const AggArgs &A, const LdsTa
       for (int j = 0; j < VM_R; ++j) G.key[j] |= (S[0].v[j] & fmask) << sh;
     } else if constexpr (role == ROLE_LOOKUP) {
       if (__ballot(c.active != 0) == 0) return;
-      spill_lookup(L, c.active, G, sp);
+      spill_lookup(L, c.active, G, sp, hist, A.cell_bits);
       if constexpr (Spec::n_accs > SPILL_ROW_MAJOR_ACCS || Spec::n_accs == 0) {
 #pragma unroll
         for (int j = 0; j < VM_R; ++j)
@@ -830,7 +833,7 @@ __device__ __forceinline__ void spill_tasks_static(const AggArgs &A, const LdsTa
         if (__ballot(G.hit != 0) != 0) spill_fold_acc<Spec, (int)idx, 0>(L, S[0], G);
       }
     }
-    spill_tasks_static<Spec, T + 1>(A, L, c, K, G, in, sp);
+    spill_tasks_static<Spec, T + 1>(A, L, c, K, G, in, sp, hist);
   } else {
     if constexpr (Spec::n_accs <= SPILL_ROW_MAJOR_ACCS && Spec::n_accs > 0) {
       if (__ballot(G.hit != 0) != 0) spill_fold_rows<Spec, 0>(L, in, G);
@@ -848,6 +851,9 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_spill_static
   LdsTable L;
   agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, Spec::n_accs, spec_tracks_validity<Spec>());
   if (A.door_off != 0) L.door = (uint16_t *)((char *)lds_raw + A.door_off);
+  uint32_t *hist = A.cells != nullptr ? (uint32_t *)((char *)lds_raw + A.hist_off) : nullptr;
+  if (hist)
+    for (uint32_t p = threadIdx.x; p < (1u << A.cell_bits); p += blockDim.x) hist[p] = 0;
   agg_lds_clear(L, A.accs, Spec::n_accs);  // ends with a barrier
   SpillState sp = spill_begin(A.spill, wave);
   const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
@@ -866,9 +872,15 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_spill_static
     G.miss = 0;
     G.pos = 0;
     Slot in[Spec::n_accs > 0 && Spec::n_accs <= SPILL_ROW_MAJOR_ACCS ? Spec::n_accs : 1];
-    spill_tasks_static<Spec, 0>(A, L, c, K, G, in, sp);
+    spill_tasks_static<Spec, 0>(A, L, c, K, G, in, sp, hist);
   }
   spill_end(A.spill, sp, wave, lane);
+  if (hist) {
+    // this workgroup's column of the partition passes' cell table, and its share of the log's length
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < (1u << A.cell_bits); p += blockDim.x) A.cells[(size_t)p * gridDim.x + blockIdx.x] = (int32_t)hist[p];
+    if (lane == 0 && sp.cursor != 0) atomicAdd(A.cells_total, (unsigned long long)sp.cursor);
+  }
   if (!(A.tune & 4u)) agg_flush(L, A.table, A.accs, Spec::n_accs);  // (bit 2: timing experiments)
 }
 

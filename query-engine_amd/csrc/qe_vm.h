@@ -218,6 +218,11 @@ struct AggSpill {
   uint64_t capacity;
   uint32_t rows_per_wave;    // size of one wave's region
   uint32_t n_inputs;
+  // How the partition passes deal the log's segments (one per first-pass wave) to their workgroups: 0 = round-robin
+  // (workgroup b takes b, b + blocks, ...), n = runs of n (workgroup b takes [b n, (b + 1) n): the segments of first-pass
+  // workgroup b, which is what lets that workgroup count its own rows per partition).
+  uint32_t seg_chunk;
+  uint32_t seg_pad;
 };
 
 struct AggArgs {
@@ -237,6 +242,13 @@ struct AggArgs {
   uint8_t spill_col[VM_MAX_ACCS];  // value column an accumulator's input is logged to; 0xff: not this one
   uint32_t block_threads;          // host only: threads per workgroup of the launch (0 = VM_BLOCK_THREADS)
   uint32_t door_off;               // byte offset of the admission tags in dynamic LDS (high-cardinality mode); 0 = none
+  // High-cardinality first pass counting its logged rows per partition as it goes (saves the count pass over the log):
+  // cells[p * gridDim.x + blockIdx.x] = rows of partition p this workgroup logged, *cells_total += rows logged;
+  // the histogram lives at hist_off in dynamic LDS.  cells == nullptr: not asked for.
+  int32_t *cells;
+  unsigned long long *cells_total;
+  int32_t cell_bits;
+  uint32_t hist_off;
   uint32_t tune;                   // bit 0: no hot keys in registers for this launch; bit 1 (host): the caller promised many groups
   uint32_t tune_pad;
 };
