@@ -584,7 +584,7 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
         return list(qe.AggregateExec([proj], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None)],
                                      group_capacity_hint=1_100_000).execute())[0]
     dt, prof, out = timed(ctx, torch, c5m, 3, 1)
-    entry("C5_plan_1M_groups_500M", r5, dt, prof, "qe_aggregate_static", BYTES_PER_ROW["c5"], len(b5),
+    entry("C5_plan_1M_groups_500M", r5, dt, prof, "qe_aggregate_spill_static", BYTES_PER_ROW["c5"], len(b5),
           {"groups": out.num_rows}, steps=3)
     del uk, b5, out
 
@@ -601,7 +601,7 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
                                      [qe.SumExpression(C(1)), qe.MinExpression(C(1)), qe.MaxExpression(C(1)), qe.AvgExpression(C(1))],
                                      group_capacity_hint=1_100_000).execute())[0]
     dt, prof, out = timed(ctx, torch, c4, 2, 1)
-    entry("C4_groupby_zipf_1Mkeys_500M", r4, dt, prof, "qe_aggregate_static", BYTES_PER_ROW["c4"], len(b4),
+    entry("C4_groupby_zipf_1Mkeys_500M", r4, dt, prof, "qe_aggregate_spill_static", BYTES_PER_ROW["c4"], len(b4),
           {"groups": out.num_rows, "note": "not HBM bound: see kernels_ms_per_step"}, steps=2)
     del zk, b4, out
 
