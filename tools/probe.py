@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small single-GPU driver for profiling one configuration under rocprofv3.
 
-usage: probe.py <c2|c3|c5|c4> [rows] [reps]
+usage: probe.py <c2|c3|c5|c4|c5m|p> [rows] [reps]   (c5m: the c5 plan over 1 M uniform keys)
 """
 import importlib
 import os
@@ -28,6 +28,8 @@ def main():
     c = torch.empty(n, dtype=torch.float64, device=dev)
     if cfg == "c4":
         ctx.generate(2, 77, 0, n, 1_000_000, 1.1, k.data_ptr())
+    elif cfg == "c5m":
+        ctx.generate(1, 99, 0, n, 0, 1_000_000, k.data_ptr())
     else:
         ctx.generate(3, 43, 0, n, 0, 0, k.data_ptr())
     ctx.generate(0, 44, 0, n, -1.0, 1.0, a.data_ptr())
@@ -51,7 +53,8 @@ def main():
             return qe.ProjectionExec([scan], [qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
         sel = qe.SelectionExec([scan], qe.GtExpression(C(3), qe.LiteralFloatExpression(0.5)))
         proj = qe.ProjectionExec([sel], [C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
-        return qe.AggregateExec([proj], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None)], group_capacity_hint=64)
+        return qe.AggregateExec([proj], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None)],
+                                group_capacity_hint=1_100_000 if cfg == "c5m" else 64)
 
     out = list(plan().execute())[0]
     torch.cuda.synchronize()
