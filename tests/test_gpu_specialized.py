@@ -163,6 +163,49 @@ def test_high_cardinality_mode(qe, ctx, n, n_keys, zipf):
         assert "qe_aggregate_partitioned_kernel" in names, names
 
 
+def test_lean_first_pass_of_the_high_cardinality_mode(qe):
+    """With a hint of many groups the first pass is a kernel of its own (qe_aggregate_spill_static / _spill_jit) that
+    also counts its logged rows per partition (no qe_spill_count_kernel).  Against the oracle: the pre-built shape, a
+    run-time compiled shape with six accumulators over three inputs (folded accumulator by accumulator, not row by row),
+    the key equal to the table's empty marker, NaN inputs of min / max, two batches into one table."""
+    jit = qe.Context(0)
+    jit.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_JIT_SYNC)
+    try:
+        n, n_keys = 1_200_000, 300_000  # (a batch of at least 2^20 rows: smaller ones are not worth a run-time compile)
+        r = rng(7)
+        k = (r.zipf(1.2, n) % n_keys).astype(np.int64) * 2654435761 % (2 ** 40)
+        k[::1000] = -1  # all ones: the marker of an empty table slot, kept in a slot of its own
+        z = r.uniform(-100, 100, n)
+        x = z.copy()
+        x[5::997] = np.nan  # min / max skip NaN
+        y = r.integers(-2 ** 40, 2 ** 40, n)
+        jit.profile(True)
+        jit.profile_read()
+        hint = 400_000
+        # the pre-built shape: (k, z) -> SUM, MIN, MAX, AVG of z, two batches into one table
+        kz = [orc.Array(orc.INT64, k), orc.Array(orc.FLOAT64, z)]
+        four = [("sum", C(1)), ("min", C(1)), ("max", C(1)), ("avg", C(1))]
+        run_agg(qe, jit, [kz], [C(0)], four, hint=hint, what="lean four")
+        names = set(jit.profile_read())
+        assert any(k.startswith("qe_aggregate_spill_static<") for k in names), names
+        assert "qe_spill_count_kernel" not in names and "qe_aggregate_partitioned_kernel" in names, names
+        # (a small second batch: too few workgroups for one per column of the cell table, so its rows are counted by the count pass)
+        run_agg(qe, jit, [kz, [orc.Array(a.type, a.values[:50_000]) for a in kz]], [C(0)], four, hint=hint, what="lean four, two batches")
+        assert "qe_spill_count_kernel" in set(jit.profile_read())
+        # a run-time compiled shape: seven aggregates over three inputs behind a filter
+        cols = [orc.Array(orc.INT64, k), orc.Array(orc.FLOAT64, z), orc.Array(orc.FLOAT64, x), orc.Array(orc.INT64, y)]
+        second = [orc.Array(a.type, a.values[:50_000]) for a in cols]
+        seven = [("sum", C(1)), ("min", C(2)), ("max", C(3)), ("sum", C(3)), ("min", C(3)), ("max", C(2)), ("avg", C(1))]
+        run_agg(qe, jit, [cols], [C(0)], seven, pred=("gt", C(3), ("i64", -2 ** 39)), hint=hint, what="lean seven")
+        names = set(jit.profile_read())
+        assert any(k.startswith("qe_aggregate_spill_jit<") for k in names), names
+        assert "qe_spill_count_kernel" not in names, names
+        run_agg(qe, jit, [cols, second], [C(0)], seven, pred=("gt", C(3), ("i64", -2 ** 39)), hint=hint, what="lean seven, two batches")
+    finally:
+        jit.profile(False)
+        jit.close()
+
+
 def test_many_groups_without_a_hint(qe, ctx):
     """A million groups and no group-count hint from the caller: the default table fills up, is given up at once
     (not walked slot by slot for every further key, which took minutes), and the second attempt - sized, and
