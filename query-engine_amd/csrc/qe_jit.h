@@ -29,8 +29,9 @@ bool jit_launch(JitKind kind, const SpecFields &fields, const void *args, int mo
                 size_t lds_bytes, hipStream_t stream, hipError_t *err, const char **kernel_name);
 
 // Is the kernel for this shape ready to launch?  In JIT_SYNC mode it is compiled now if need be; otherwise this only
-// looks (and starts nothing).
-bool jit_ready(JitKind kind, const SpecFields &fields, int mode);
+// looks - and, with `start_if_absent`, starts the background compilation of a shape it has not seen (for kernels
+// that no launch would otherwise ask for: a caller that picks its launch geometry by what is ready).
+bool jit_ready(JitKind kind, const SpecFields &fields, int mode, bool start_if_absent = false);
 
 // Compiles the kernel for `fields` without touching a device; returns the code object's size.
 // Throws qe::Failure when the compiler rejects the source (the log is the message).

@@ -1160,7 +1160,8 @@ bool aggregate_wide_available(const AggArgs &args, const DeviceInfo &dev) {
   if (enabled == 2 || !dev.specialised) return false;
   if (static_has_aggregate(args)) return true;
   if (!jit_wanted(dev, args.n_rows)) return false;
-  return (args.tune & 2u) ? jit_ready(JIT_AGGREGATE_SPILL, spec_fields_spill(args), dev.jit) : jit_ready(JIT_AGGREGATE, spec_fields(args), dev.jit);
+  // (the first-pass kernel of the many-groups mode is asked for by nobody else: its background compilation starts here)
+  return (args.tune & 2u) ? jit_ready(JIT_AGGREGATE_SPILL, spec_fields_spill(args), dev.jit, true) : jit_ready(JIT_AGGREGATE, spec_fields(args), dev.jit);
 }
 
 // Dense-key bins (see qe_static.h) for aggregates with few groups whose inputs cannot be null, when

@@ -205,17 +205,41 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_project_static(const P
 }
 
 // ------------------------------------------------------------------- filter
+// A wave-step's selected values of an 8-byte column that cannot be null go out through the wave's LDS staging row:
+// every lane drops its values at their ranks, then takes two neighbours back and writes 16 bytes - one full store
+// instruction per 128 values instead of four instructions that each fill a fraction of the same cache lines.
+struct alignas(8) U64Pair8 {
+  uint64_t x, y;
+};
+
 template <class Spec, int E>
 __device__ __forceinline__ void filter_outs_static(const FilterArgs &A, const RowCtx &c, const ColCache &K, unsigned long long obase,
-                                                   uint32_t sel, const uint32_t (&rank)[VM_R]) {
+                                                   uint32_t sel, const uint32_t (&rank)[VM_R], uint64_t *stage, uint32_t cnt) {
   if constexpr (E < Spec::n_outs) {
     Slot S[VM_MAX_DEPTH];
     eval_static<Spec, Spec::out_pc[E]>(A.prog, c, K, S);
     VmOut o = A.outs[E];
     o.type = (uint8_t)Spec::out_type[E];
     if constexpr (Spec::out_nullable[E] == 0) o.validity = nullptr;
-    store_compact(o, obase, sel, rank, S[0]);
-    filter_outs_static<Spec, E + 1>(A, c, K, obase, sel, rank);
+    if constexpr (Spec::out_nullable[E] == 0 && (Spec::out_type[E] == VT_I64 || Spec::out_type[E] == VT_F64)) {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j)
+        if ((sel >> j) & 1u) stage[rank[j]] = S[0].v[j];
+      uint64_t *out = (uint64_t *)o.values + obase;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t i = (uint32_t)h * 128u + 2u * c.lane;
+        if (i + 1 < cnt) {
+          const U64Pair8 two = *(const U64Pair8 *)(stage + i);
+          *(U64Pair8 *)(out + i) = two;
+        } else if (i < cnt) {
+          out[i] = stage[i];
+        }
+      }
+    } else {
+      store_compact(o, obase, sel, rank, S[0]);
+    }
+    filter_outs_static<Spec, E + 1>(A, c, K, obase, sel, rank, stage, cnt);
   }
 }
 
@@ -245,6 +269,7 @@ __global__ __launch_bounds__(FilterGeometry<Spec>::WAVES * 64, 1) void qe_filter
   __shared__ unsigned long long s_tile;
   __shared__ unsigned long long s_base;
   __shared__ uint32_t s_cnt[STEPS * WAVES];
+  __shared__ __attribute__((aligned(16))) uint64_t s_stage[WAVES][VM_WAVE_ROWS];  // a wave's selected values on their way out
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   const int64_t n = A.n_rows;
@@ -302,7 +327,7 @@ __global__ __launch_bounds__(FilterGeometry<Spec>::WAVES * 64, 1) void qe_filter
       if (__ballot(sel[s] != 0) == 0) continue;
       uint32_t rank[VM_R];
       rank_rows(sel[s], rank);
-      filter_outs_static<Spec, 0>(A, c[s], K[s], base + pref[s], sel[s], rank);
+      filter_outs_static<Spec, 0>(A, c[s], K[s], base + pref[s], sel[s], rank, s_stage[wave], s_cnt[s * WAVES + wave]);
     }
   }
 }
