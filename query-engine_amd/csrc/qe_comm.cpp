@@ -272,27 +272,36 @@ qe_status qe_exchange_all_gather(qe_comm *comm, const qe_batch *partial, int64_t
     result.ctx = ctx;
     result.rows = padded_rows * C.world;
     Rccl &R = rccl();
-    // every rank's block lands at rank * padded_rows of the output column: this rank's own block is put there first
-    // (zero beyond its rows) and the collective runs in place
+    // Every rank's block lands at rank * padded_rows of the output column.  A table that already has the padded size
+    // (the deferred mode's one-row-per-slot block) is sent from where it lies; a shorter one is first put into its place
+    // in the output, zero beyond its rows, and the collective runs in place.
+    const bool as_it_is = in.rows == padded_rows && padded_rows > 0;
     for (auto &c : in.cols) {
       const size_t w = (size_t)type_width(c.type);
       Column o = exchange_column(ctx, c.type, result.rows, c.validity != nullptr);
-      char *mine = (char *)o.values->ptr + (size_t)C.rank * padded_rows * w;
-      if (in.rows) QE_HIP(hipMemcpyAsync(mine, c.values_ptr(), (size_t)in.rows * w, hipMemcpyDeviceToDevice, ctx->stream));
-      if (padded_rows > in.rows) QE_HIP(hipMemsetAsync(mine + (size_t)in.rows * w, 0, (size_t)(padded_rows - in.rows) * w, ctx->stream));
-      if (c.validity) {
-        char *vb = (char *)o.validity->ptr + (size_t)C.rank * (padded_rows / 8);
-        QE_HIP(hipMemsetAsync(vb, 0, (size_t)(padded_rows / 8), ctx->stream));
-        if (in.rows) QE_HIP(hipMemcpyAsync(vb, c.validity_ptr(), (size_t)((in.rows + 7) / 8), hipMemcpyDeviceToDevice, ctx->stream));
+      if (!as_it_is) {
+        char *mine = (char *)o.values->ptr + (size_t)C.rank * padded_rows * w;
+        if (in.rows) QE_HIP(hipMemcpyAsync(mine, c.values_ptr(), (size_t)in.rows * w, hipMemcpyDeviceToDevice, ctx->stream));
+        if (padded_rows > in.rows) QE_HIP(hipMemsetAsync(mine + (size_t)in.rows * w, 0, (size_t)(padded_rows - in.rows) * w, ctx->stream));
+        if (c.validity) {
+          char *vb = (char *)o.validity->ptr + (size_t)C.rank * (padded_rows / 8);
+          QE_HIP(hipMemsetAsync(vb, 0, (size_t)(padded_rows / 8), ctx->stream));
+          if (in.rows) QE_HIP(hipMemcpyAsync(vb, c.validity_ptr(), (size_t)((in.rows + 7) / 8), hipMemcpyDeviceToDevice, ctx->stream));
+        }
       }
       result.cols.push_back(o);
     }
     QE_NCCL(R.GroupStart());
-    for (auto &o : result.cols) {
+    for (size_t ci = 0; ci < result.cols.size(); ++ci) {
+      Column &o = result.cols[ci];
+      const Column &c = in.cols[ci];
       const size_t block = (size_t)padded_rows * type_width(o.type);
-      if (block) QE_NCCL(R.AllGather((char *)o.values->ptr + (size_t)C.rank * block, o.values->ptr, block, NCCL_UINT8, C.comm, ctx->stream));
-      if (o.validity && padded_rows)
-        QE_NCCL(R.AllGather((char *)o.validity->ptr + (size_t)C.rank * (padded_rows / 8), o.validity->ptr, (size_t)(padded_rows / 8), NCCL_UINT8, C.comm, ctx->stream));
+      const void *send = as_it_is ? c.values_ptr() : (const void *)((char *)o.values->ptr + (size_t)C.rank * block);
+      if (block) QE_NCCL(R.AllGather(send, o.values->ptr, block, NCCL_UINT8, C.comm, ctx->stream));
+      if (o.validity && padded_rows) {
+        const void *vsend = as_it_is ? (const void *)c.validity_ptr() : (const void *)((char *)o.validity->ptr + (size_t)C.rank * (padded_rows / 8));
+        QE_NCCL(R.AllGather(vsend, o.validity->ptr, (size_t)(padded_rows / 8), NCCL_UINT8, C.comm, ctx->stream));
+      }
     }
     QE_NCCL(R.GroupEnd());
     *out = qe_batch_wrap(result);

@@ -74,6 +74,38 @@ def test_partial_all_gather_final(qe, ctx, comm, n, n_keys):
         comm.all_gather(partial, partial.num_rows - 1)  # padded_rows below the table's rows
 
 
+def test_all_gather_of_a_table_that_has_the_padded_size(qe, ctx, comm):
+    """padded_rows == the table's rows (what the deferred mode's one-row-per-slot block gives): the columns are sent from
+    where they lie, no copy into place first.  With the deferred flag on, as bench.py uses it."""
+    k, a, b, c = _table(150_000, 40, seed=6)
+    batch = qe.Batch.from_numpy(ctx, [k, a, b, c])
+    ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_DEFERRED_GROUP_COUNT)
+    try:
+        C = qe.ColumnExpression
+        sel = qe.SelectionExec([qe.ScanExec(ctx, [batch])], qe.GtExpression(C(3), qe.LiteralFloatExpression(0.5)))
+        proj = qe.ProjectionExec([sel], [C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
+        aggs = [qe.SumExpression(C(1)), qe.CountExpression(None)]
+        partial = list(qe.AggregateExec([proj], [C(0)], aggs, mode=qe.AGG_MODE_PARTIAL, group_capacity_hint=64).execute())[0]
+        assert partial.num_rows > 40  # one row per table slot
+        for _ in range(2):
+            gathered = comm.all_gather(partial, partial.num_rows)
+        real = qe.SelectionExec([qe.ScanExec(ctx, [gathered])], qe.GtExpression(C(2), qe.LiteralInt64Expression(0)))
+        merged = list(qe.final_plan(real, 1, aggs, group_capacity_hint=64).execute())[0]
+        ctx.synchronize()
+    finally:
+        ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP)
+    got = merged.columns()
+    real_rows = np.asarray(got[2].values) > 0
+    keep = c > 0.5
+    v = a + b * c
+    uk, inv = np.unique(k[keep], return_inverse=True)
+    order = np.argsort(np.asarray(got[0].values)[real_rows])
+    assert np.array_equal(np.asarray(got[0].values)[real_rows][order], uk)
+    assert np.array_equal(np.asarray(got[2].values)[real_rows][order], np.bincount(inv))
+    want = np.bincount(inv, weights=v[keep])
+    assert (np.abs(np.asarray(got[1].values)[real_rows][order] - want) <= REL * np.bincount(inv, weights=np.abs(v[keep]))).all()
+
+
 @pytest.mark.parametrize("n,n_keys", [(300_000, 2_000), (2_000_000, 150_000)])
 def test_partial_exchange_by_key_final(qe, ctx, comm, n, n_keys):
     k, a, b, c = _table(n, n_keys, seed=4)
