@@ -156,7 +156,9 @@ static Column utf8_gather_column(Context *ctx, const Column &src, const int64_t 
   c.values_bytes = total;
   c.values = device_buffer(ctx, (size_t)total + 16);
   ctx->prof_begin("qe_utf8_gather_bytes_kernel");
-  QE_HIP(launch_utf8_gather_bytes(src.offsets_ptr(), (const uint8_t *)src.values_ptr(), idx, m, offs,
+  // (the source's bytes as its buffer bounds them: a 16-byte fetch of a short row must end inside)
+  const int64_t src_total = src.values ? (int64_t)std::max<size_t>(src.values->bytes, (size_t)std::max<int64_t>(src.values_bytes, 0)) : 0;
+  QE_HIP(launch_utf8_gather_bytes(src.offsets_ptr(), (const uint8_t *)src.values_ptr(), src_total, idx, m, offs,
                                   (uint8_t *)c.values->ptr, ctx->stream));
   ctx->prof_end();
   return c;
