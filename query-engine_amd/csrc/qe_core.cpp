@@ -155,7 +155,7 @@ unsigned long long *Context::deferred_sink() {
   bind();
   if (!counters) {
     QE_HIP(hipMalloc((void **)&counters, 64 * sizeof(unsigned long long)));
-    QE_HIP(hipHostMalloc((void **)&host_counters, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+    QE_HIP(hipHostMalloc((void **)&host_counters, 128 * sizeof(unsigned long long), hipHostMallocDefault));
   }
   if (!deferred_pending) {
     QE_HIP(hipMemsetAsync(counters + 40, 0, sizeof(unsigned long long), stream));

@@ -102,7 +102,7 @@ static void ensure_filter_scratch(Context *ctx, int64_t n_rows) {
 static void ensure_counters(Context *ctx) {
   if (!ctx->counters) {
     QE_HIP(hipMalloc((void **)&ctx->counters, 64 * sizeof(unsigned long long)));
-    QE_HIP(hipHostMalloc((void **)&ctx->host_counters, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+    QE_HIP(hipHostMalloc((void **)&ctx->host_counters, 128 * sizeof(unsigned long long), hipHostMallocDefault));
   }
 }
 
@@ -126,42 +126,71 @@ static Column utf8_broadcast_column(Context *ctx, const std::string &s, int64_t 
   return c;
 }
 
-static Column utf8_gather_column(Context *ctx, const Column &src, const int64_t *idx, int64_t m) {
-  Column c;
-  c.type = QE_TYPE_UTF8;
-  c.space = QE_MEM_DEVICE;
-  c.length = m;
-  c.offsets = device_buffer(ctx, (size_t)(m + 1) * 4 + 16);
-  if (src.validity) {
-    size_t bb = bitmap_bytes(m);
-    c.validity = device_buffer(ctx, bb);
-    QE_HIP(hipMemsetAsync(c.validity->ptr, 0, bb, ctx->stream));
-    c.null_count = -1;
-  }
-  int32_t *offs = (int32_t *)c.offsets->ptr;
-  // lengths -> offs[0..m), then exclusive scan over m+1 entries gives offs[m] = total
-  QE_HIP(hipMemsetAsync(offs + m, 0, 4, ctx->stream));
-  ctx->prof_begin("qe_utf8_gather_lengths_kernel");
-  QE_HIP(launch_utf8_gather_lengths(src.offsets_ptr(), src.validity_ptr(), idx, m, offs,
-                                    c.validity ? (uint32_t *)c.validity->ptr : nullptr, ctx->stream));
-  ctx->prof_end();
-  BufferPtr scan_tmp = device_buffer(ctx, scan_scratch_elems(m + 1) * 4 + 64);
-  ctx->prof_begin("qe_scan_kernels");
-  QE_HIP(launch_exclusive_scan_i32(offs, m + 1, (int32_t *)scan_tmp->ptr, ctx->stream));
-  ctx->prof_end();
+// Rows idx[0..m) of several utf8 columns.  The offsets of a group of columns are computed first, their byte totals come
+// back with one synchronisation, then the bytes are copied: the host waits once per group, not once per column.
+static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<const Column *> &srcs, const int64_t *idx, int64_t m) {
+  constexpr size_t GROUP = 6, FIRST_WORD = 64, CONTROL_WORDS = 8;  // a column's control block: ticket, byte total, look-back error, padding
+  static_assert(CONTROL_WORDS * sizeof(unsigned long long) == sizeof(FilterScratch), "control block");
+  std::vector<Column> out(srcs.size());
   ensure_counters(ctx);
-  QE_HIP(hipMemcpyAsync(ctx->host_counters + 8, offs + m, 4, hipMemcpyDeviceToHost, ctx->stream));
-  ctx->sync();
-  int32_t total = *(int32_t *)(ctx->host_counters + 8);
-  c.values_bytes = total;
-  c.values = device_buffer(ctx, (size_t)total + 16);
-  ctx->prof_begin("qe_utf8_gather_bytes_kernel");
-  // (the source's bytes as its buffer bounds them: a 16-byte fetch of a short row must end inside)
-  const int64_t src_total = src.values ? (int64_t)std::max<size_t>(src.values->bytes, (size_t)std::max<int64_t>(src.values_bytes, 0)) : 0;
-  QE_HIP(launch_utf8_gather_bytes(src.offsets_ptr(), (const uint8_t *)src.values_ptr(), src_total, idx, m, offs,
-                                  (uint8_t *)c.values->ptr, ctx->stream));
-  ctx->prof_end();
-  return c;
+  const size_t status_bytes = m > 0 ? (utf8_gather_offsets_status_bytes(m) + 63) / 64 * 64 : 0;
+  for (size_t g0 = 0; g0 < srcs.size(); g0 += GROUP) {
+    const size_t g1 = std::min(srcs.size(), g0 + GROUP), cols = g1 - g0;
+    BufferPtr scratch;  // the group's control blocks, then its status arrays
+    if (m > 0) {
+      const size_t sb = cols * (sizeof(FilterScratch) + status_bytes);
+      scratch = device_buffer(ctx, sb);
+      QE_HIP(hipMemsetAsync(scratch->ptr, 0, sb, ctx->stream));
+    }
+    for (size_t j = g0; j < g1; ++j) {
+      const Column &src = *srcs[j];
+      Column &c = out[j];
+      c.type = QE_TYPE_UTF8;
+      c.space = QE_MEM_DEVICE;
+      c.length = m;
+      c.offsets = device_buffer(ctx, (size_t)(m + 1) * 4 + 16);
+      if (src.validity) {
+        size_t bb = bitmap_bytes(m);
+        c.validity = device_buffer(ctx, bb);
+        QE_HIP(hipMemsetAsync(c.validity->ptr, 0, bb, ctx->stream));
+        c.null_count = -1;
+      }
+      int32_t *offs = (int32_t *)c.offsets->ptr;
+      if (m <= 0) {
+        QE_HIP(hipMemsetAsync(offs, 0, 4, ctx->stream));
+        continue;
+      }
+      // lengths by row id, scanned into offsets, in one pass; offs[m] = the byte total
+      ctx->prof_begin("qe_utf8_gather_offsets_kernel");
+      QE_HIP(launch_utf8_gather_offsets(src.offsets_ptr(), src.validity_ptr(), idx, m, offs, c.validity ? (uint32_t *)c.validity->ptr : nullptr,
+                                        (char *)scratch->ptr + (j - g0) * sizeof(FilterScratch),
+                                        (char *)scratch->ptr + cols * sizeof(FilterScratch) + (j - g0) * status_bytes, ctx->dev.cus, ctx->stream));
+      ctx->prof_end();
+    }
+    if (m > 0) {
+      QE_HIP(hipMemcpyAsync(ctx->host_counters + FIRST_WORD, scratch->ptr, cols * sizeof(FilterScratch), hipMemcpyDeviceToHost, ctx->stream));
+      ctx->sync();  // (the scratch block is done with here too)
+    }
+    for (size_t j = g0; j < g1; ++j) {
+      const Column &src = *srcs[j];
+      Column &c = out[j];
+      int32_t total = 0;
+      if (m > 0) {
+        const unsigned long long *w = ctx->host_counters + FIRST_WORD + CONTROL_WORDS * (j - g0);
+        if (w[2] != 0) fail(QE_ERR_INTERNAL, "string gather look-back timed out");
+        total = (int32_t)w[1];
+      }
+      c.values_bytes = total;
+      c.values = device_buffer(ctx, (size_t)total + 16);
+      ctx->prof_begin("qe_utf8_gather_bytes_kernel");
+      // (the source's bytes as its buffer bounds them: a 16-byte fetch of a short row must end inside)
+      const int64_t src_total = src.values ? (int64_t)std::max<size_t>(src.values->bytes, (size_t)std::max<int64_t>(src.values_bytes, 0)) : 0;
+      QE_HIP(launch_utf8_gather_bytes(src.offsets_ptr(), (const uint8_t *)src.values_ptr(), src_total, idx, m, (const int32_t *)c.offsets->ptr,
+                                      (uint8_t *)c.values->ptr, ctx->stream));
+      ctx->prof_end();
+    }
+  }
+  return out;
 }
 
 // A utf8 column of one scanned batch and the global row number of its first row.
@@ -503,7 +532,12 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
   }
   out.rows = m;
   for (int i : vm_list) finish_fixed_column(out.cols[i], m);
-  for (int i : utf8_cols) out.cols[i] = utf8_gather_column(ctx, in.cols[outs[i]->index], (const int64_t *)rowid.values->ptr, m);
+  if (!utf8_cols.empty()) {
+    std::vector<const Column *> srcs;
+    for (int i : utf8_cols) srcs.push_back(&in.cols[outs[i]->index]);
+    std::vector<Column> got = utf8_gather_columns(ctx, srcs, (const int64_t *)rowid.values->ptr, m);
+    for (size_t j = 0; j < utf8_cols.size(); ++j) out.cols[utf8_cols[j]] = std::move(got[j]);
+  }
   for (int i : utf8_lits) out.cols[i] = utf8_broadcast_column(ctx, outs[i]->sval, m);
   if (need_rowid) ctx->sync();  // rowid buffer goes back to the pool on return
   return out;

@@ -64,6 +64,12 @@ hipError_t launch_utf8_gather_lengths(const int32_t *offsets, const uint8_t *val
                                       int32_t *out_lengths, uint32_t *out_validity, hipStream_t stream);
 hipError_t launch_exclusive_scan_i32(int32_t *data, int64_t n, int32_t *block_sums, hipStream_t stream);
 size_t scan_scratch_elems(int64_t n);
+// Output offsets (out_offsets[0..m]) and validity bits of rows idx[0..m) of a string column in one launch.  control:
+// 64 zeroed bytes whose second word receives the byte total and whose third is non-zero if the look-back gave up;
+// status: utf8_gather_offsets_status_bytes(m) zeroed bytes.
+size_t utf8_gather_offsets_status_bytes(int64_t m);
+hipError_t launch_utf8_gather_offsets(const int32_t *src_offsets, const uint8_t *src_validity, const int64_t *idx, int64_t m, int32_t *out_offsets,
+                                      uint32_t *out_validity, void *control, void *status, int cus, hipStream_t stream);
 hipError_t launch_utf8_gather_bytes(const int32_t *src_offsets, const uint8_t *src_bytes, int64_t src_total, const int64_t *idx, int64_t m,
                                     const int32_t *dst_offsets, uint8_t *dst_bytes, hipStream_t stream);
 // Gather of strings by global row number over several source columns (group-by output keys).

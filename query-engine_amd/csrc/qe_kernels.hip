@@ -832,6 +832,80 @@ __global__ void qe_utf8_gather_lengths_kernel(const int32_t *offsets, const uint
   }
 }
 
+// Output offsets of the selected rows of a string column in one pass: lengths by row id, scanned within a tile of 4096
+// rows, the tile's first byte from a decoupled look-back over the tiles' byte counts (the filter's protocol: tiles
+// handed out by a ticket counter, one status word a tile), validity bits gathered on the way.  Replaces a lengths
+// kernel and a three-kernel scan over an intermediate array.  scratch and status (a word per tile) start zeroed;
+// scratch->total receives the byte count, out_offsets[m] too.
+constexpr int OFFSETS_THREADS = 1024, OFFSETS_TILE = 4096;
+__global__ __launch_bounds__(OFFSETS_THREADS) void qe_utf8_gather_offsets_kernel(const int32_t *src_offsets, const uint8_t *src_validity, const int64_t *idx,
+                                                                                   int64_t m, int64_t n_tiles, int32_t *out_offsets, uint32_t *out_validity,
+                                                                                   FilterScratch *scratch, unsigned long long *status) {
+  __shared__ int32_t s_wave[OFFSETS_THREADS / 64];
+  __shared__ unsigned long long s_tile, s_base;
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(&scratch->ticket, 1ull);
+    __syncthreads();
+    const int64_t tile = (int64_t)s_tile;
+    if (tile >= n_tiles) break;
+    const int64_t i0 = tile * OFFSETS_TILE + (int64_t)threadIdx.x * 4;
+    int64_t r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = i0 + k < m ? idx[i0 + k] : -1;
+    int32_t len[4];
+    int32_t sum = 0;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      len[k] = 0;
+      if (r[k] >= 0) {
+        len[k] = src_offsets[r[k] + 1] - src_offsets[r[k]];
+        if (out_validity) bits |= ((src_validity[r[k] >> 3] >> (r[k] & 7)) & 1u) << k;
+      }
+      sum += len[k];
+    }
+    if (out_validity) {  // eight lanes hold the 32 rows of one output word
+      uint32_t w = bits << (4 * (lane & 7));
+      w |= __shfl_xor(w, 1);
+      w |= __shfl_xor(w, 2);
+      w |= __shfl_xor(w, 4);
+      if ((lane & 7) == 0 && i0 < m) out_validity[i0 >> 5] = w;
+    }
+    int32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t t = __shfl_up(incl, o);
+      if ((int)lane >= o) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < OFFSETS_THREADS / 64; ++w) {
+      if ((uint32_t)w < wave) woff += s_wave[w];
+      total += s_wave[w];
+    }
+    if (wave == 0) {
+      const unsigned long long excl = lookback_exclusive(status, tile, (unsigned long long)total, lane, &scratch->error);
+      if (lane == 0) {
+        s_base = excl;
+        if (tile == n_tiles - 1) {
+          scratch->total = excl + (unsigned long long)total;
+          out_offsets[m] = (int32_t)(excl + (unsigned long long)total);
+        }
+      }
+    }
+    __syncthreads();
+    int32_t run = (int32_t)s_base + woff + incl - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k < m) out_offsets[i0 + k] = run;
+      run += len[k];
+    }
+  }
+}
+
 constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
@@ -1406,6 +1480,18 @@ hipError_t launch_utf8_gather_lengths(const int32_t *offsets, const uint8_t *val
   if (m <= 0) return hipSuccess;
   hipLaunchKernelGGL(qe_utf8_gather_lengths_kernel, dim3(grid_for(m, 256, 4096)), dim3(256), 0, stream, offsets,
                      validity, idx, m, out_lengths, validity ? out_validity : nullptr);
+  return hipGetLastError();
+}
+
+size_t utf8_gather_offsets_status_bytes(int64_t m) { return (size_t)((m + OFFSETS_TILE - 1) / OFFSETS_TILE) * sizeof(unsigned long long); }
+
+hipError_t launch_utf8_gather_offsets(const int32_t *src_offsets, const uint8_t *src_validity, const int64_t *idx, int64_t m, int32_t *out_offsets,
+                                      uint32_t *out_validity, void *control, void *status, int cus, hipStream_t stream) {
+  if (m <= 0) return hipSuccess;
+  const int64_t n_tiles = (m + OFFSETS_TILE - 1) / OFFSETS_TILE;
+  const int grid = (int)(n_tiles < (int64_t)cus * 2 ? n_tiles : (int64_t)cus * 2);
+  hipLaunchKernelGGL(qe_utf8_gather_offsets_kernel, dim3(grid), dim3(OFFSETS_THREADS), 0, stream, src_offsets, src_validity, idx, m, n_tiles,
+                     out_offsets, src_validity ? out_validity : nullptr, (FilterScratch *)control, (unsigned long long *)status);
   return hipGetLastError();
 }
 

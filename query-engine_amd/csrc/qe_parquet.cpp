@@ -885,7 +885,7 @@ Batch parquet_read_row_group(Context *ctx, ParquetFile &file, int row_group, con
   ctx->bind();
   if (!ctx->counters) {
     QE_HIP(hipMalloc((void **)&ctx->counters, 64 * sizeof(unsigned long long)));
-    QE_HIP(hipHostMalloc((void **)&ctx->host_counters, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+    QE_HIP(hipHostMalloc((void **)&ctx->host_counters, 128 * sizeof(unsigned long long), hipHostMallocDefault));
   }
   unsigned long long *err = ctx->counters + 32;
   QE_HIP(hipMemsetAsync(err, 0, 2 * sizeof(unsigned long long), ctx->stream));
