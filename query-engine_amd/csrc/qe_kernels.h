@@ -60,8 +60,6 @@ hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream);
 hipError_t launch_fix_rescale(const AggTable &table, int acc, int delta, hipStream_t stream);
 
 // utf8 helpers: gather rows `idx[0..m)` of a utf8 column.
-hipError_t launch_utf8_gather_lengths(const int32_t *offsets, const uint8_t *validity, const int64_t *idx, int64_t m,
-                                      int32_t *out_lengths, uint32_t *out_validity, hipStream_t stream);
 hipError_t launch_exclusive_scan_i32(int32_t *data, int64_t n, int32_t *block_sums, hipStream_t stream);
 size_t scan_scratch_elems(int64_t n);
 // Output offsets (out_offsets[0..m]) and validity bits of rows idx[0..m) of a string column in one launch.  control:

@@ -624,3 +624,24 @@ def test_deferred_group_count(qe, ctx):
     finally:
         ctx.set_flags(default_flags)
     assert run().num_rows == 40
+
+
+def test_string_gather_over_more_tiles_than_workgroups(qe, ctx):
+    """Selection over string columns at a size where the offsets pass hands a workgroup more than one tile and
+    the byte copy meets every kind of wave: all rows short (a lane copies its row), a row beyond 64 bytes among
+    them (the search path), null rows, empty strings, and a column without a validity buffer."""
+    n = 2_600_000
+    r = np.random.default_rng(23)
+    words = [b"", b"a", b"Female", b"x" * 16, b"y" * 17, b"p" * 33, b"q" * 49, b"z" * 64, b"w" * 65, b"v" * 300]
+    p = np.array([0.1, 0.2, 0.3, 0.1, 0.1, 0.08, 0.06, 0.056, 0.002, 0.002])
+    pick = r.choice(len(words), n, p=p / p.sum())
+    lens = np.array([len(w) for w in words], np.int64)[pick]
+    offs = np.zeros(n + 1, np.int32)
+    np.cumsum(lens, out=offs[1:])
+    data = np.frombuffer(b"".join(words[i] for i in pick), np.uint8).copy()
+    flag = (r.random(n) < 0.9).astype(np.int32)
+    with_nulls = orc.Array(orc.UTF8, (offs, data), r.random(n) > 0.1)
+    without = orc.Array(orc.UTF8, (offs, data), None)
+    cols = [orc.Array(orc.INT32, flag), with_nulls, without]
+    got, want = run_both(qe, ctx, [cols], lambda m, scan: m.SelectionExec([scan], mk(m, ("eq", C(0), ("i32", 1)))), what="string gather, 2.6 M rows")
+    assert got[0].num_rows == int(flag.sum()) > 512 * 4096
