@@ -725,10 +725,10 @@ __device__ __forceinline__ void store_dense(const VmOut &o, const RowCtx &c, con
     for (int h = 0; h < 2; ++h) {
       int64_t r = c.row0 + h * 128 + 2 * (int64_t)c.lane;
       if (r < c.n) {
-        U32x2 t;
+        u32v2 t;
         t.x = (uint32_t)s.v[2 * h];
         t.y = (uint32_t)s.v[2 * h + 1];
-        *(U32x2 *)(p + r) = t;
+        __builtin_nontemporal_store(t, (u32v2 *)(p + r));
       }
     }
   } else {
@@ -737,10 +737,10 @@ __device__ __forceinline__ void store_dense(const VmOut &o, const RowCtx &c, con
     for (int h = 0; h < 2; ++h) {
       int64_t r = c.row0 + h * 128 + 2 * (int64_t)c.lane;
       if (r < c.n) {
-        U64x2 t;
+        u64v2 t;  // (written once, read by another kernel if at all: a streaming store)
         t.x = s.v[2 * h];
         t.y = s.v[2 * h + 1];
-        *(U64x2 *)(p + r) = t;
+        __builtin_nontemporal_store(t, (u64v2 *)(p + r));
       }
     }
   }

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, 4) void qe_project_static(const P
 struct alignas(8) U64Pair8 {
   uint64_t x, y;
 };
+typedef uint64_t u64v2a8 __attribute__((ext_vector_type(2), aligned(8)));
 
 template <class Spec, int E>
 __device__ __forceinline__ void filter_outs_static(const FilterArgs &A, const RowCtx &c, const ColCache &K, unsigned long long obase,
@@ -231,7 +232,9 @@ __device__ __forceinline__ void filter_outs_static(const FilterArgs &A, const Ro
         const uint32_t i = (uint32_t)h * 128u + 2u * c.lane;
         if (i + 1 < cnt) {
           const U64Pair8 two = *(const U64Pair8 *)(stage + i);
-          *(U64Pair8 *)(out + i) = two;
+          u64v2a8 t;
+          t.x = two.x, t.y = two.y;
+          __builtin_nontemporal_store(t, (u64v2a8 *)(out + i));
         } else if (i < cnt) {
           out[i] = stage[i];
         }
@@ -753,7 +756,7 @@ __device__ __forceinline__ void spill_lookup(const LdsTable &L, uint32_t active,
 #pragma unroll
     for (int j = 0; j < VM_R; ++j) {
       if ((miss >> j) & 1u) {
-        sp.keys[G.pos + k] = G.key[j];
+        sp.keys[G.pos + k] = G.key[j];  // (a streaming store here measured slower: the partial lines of a wave no longer merge)
         if (hist) atomicAdd(&hist[hash32(G.key[j]) >> (32 - hist_bits)], 1u);  // (= partition_of: what the partition passes go by)
       }
       k += (miss >> j) & 1u;
