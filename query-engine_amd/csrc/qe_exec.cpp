@@ -178,6 +178,7 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
       if (m > 0) {
         const unsigned long long *w = ctx->host_counters + FIRST_WORD + CONTROL_WORDS * (j - g0);
         if (w[2] != 0) fail(QE_ERR_INTERNAL, "string gather look-back timed out");
+        if (w[1] > 2147483647ull) fail(QE_ERR_INVALID_ARGUMENT, "the selected strings of one column exceed 2^31 - 1 bytes: scan smaller batches");
         total = (int32_t)w[1];
       }
       c.values_bytes = total;

@@ -649,75 +649,127 @@ hipError_t launch_fix_rescale(const AggTable &table, int acc, int delta, hipStre
   return hipGetLastError();
 }
 
-// Small tables: one atomic per wave is few enough, and no barriers.
-__global__ __launch_bounds__(256) void qe_finalize_small_kernel(const FinalizeArgs A) {
+// Validity bits of a wave's output rows.  The occupied lanes (`occ`) write consecutive rows from `first_pos` on, lane by
+// lane: their bits are put together in the wave (`valid`: this lane's row is not null) and leave as at most three
+// word-wide atomics, not one per row - a million groups with four nullable outputs are otherwise four million atomics.
+// Called by the whole wave.
+__device__ __forceinline__ void fin_store_validity(uint32_t *validity, uint64_t occ, bool valid, unsigned long long first_pos) {
+  const uint64_t ok = __ballot(valid) & occ;
+  if (ok == 0) return;
+  const uint32_t n = (uint32_t)__popcll(occ), lane = lane_id();
+  uint64_t packed;  // bit r: the r-th occupied lane's row is valid
+  if (ok == occ) {
+    packed = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+  } else {
+    packed = ((ok >> lane) & 1ull) ? 1ull << mbcnt64(occ) : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) packed |= __shfl_xor(packed, o);
+  }
+  const uint32_t sh = (uint32_t)(first_pos & 31u);
+  if (lane < 3) {  // words 0..2 of the 96-bit value packed << sh
+    uint32_t w;
+    if (lane == 0) w = (uint32_t)(packed << sh);
+    else if (lane == 1) w = (uint32_t)(sh ? packed >> (32 - sh) : packed >> 32);
+    else w = sh ? (uint32_t)(packed >> (64 - sh)) : 0u;
+    if (w != 0) atomicOr(validity + (first_pos >> 5) + lane, w);
+  }
+}
+
+// N slots a lane (slot i[j], key k[j] with the reserved slot already told apart) to output rows pos[j], every output
+// column.  Called by the whole wave; occ[j] = its lanes that hold a group in item j, whose rows are consecutive from
+// first_pos[j] on.  Per output column all items' loads come first, then all stores.
+template <int N>
+__device__ __forceinline__ void fin_emit(const FinalizeArgs &A, const uint64_t (&i)[N], const unsigned long long (&k)[N], const bool (&occupied)[N],
+                                         const uint64_t (&occ)[N], const unsigned long long (&pos)[N], const unsigned long long (&first_pos)[N]) {
   const AggTable &T = A.table;
-  if (A.overflow_sink && blockIdx.x == 0 && threadIdx.x == 0 && T.ctrl[1]) atomicAdd(A.overflow_sink, 1ull);
-  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= T.cap;
-       i += (uint64_t)gridDim.x * blockDim.x) {
-    unsigned long long k = T.keys[i];
-    // output position: one atomic per wave for all its occupied slots, not one per slot
-    const bool occupied = k != AGG_EMPTY_KEY;
-    const uint64_t occ = __ballot(occupied);
-    unsigned long long wave_base = 0;
-    if (occ != 0 && lane_id() == (uint32_t)__builtin_ctzll(occ)) wave_base = atomicAdd(A.out_count, (unsigned long long)__popcll(occ));
-    wave_base = readlane64(wave_base, occ != 0 ? __builtin_ctzll(occ) : 0);
-    if (!occupied) continue;
-    if (i == T.cap) k = AGG_EMPTY_KEY;  // reserved slot holds the marker-valued key
-    unsigned long long pos = wave_base + mbcnt64(occ);
-    for (int o = 0; o < A.n_outs; ++o) {
-      const FinOut &f = A.outs[o];
-      uint64_t val = 0;
-      bool valid = true;
-      unsigned long long cnt = f.cnt_src == CNT_ROWS  ? T.rowcnt[i]
-                               : f.cnt_src == CNT_NN ? T.nn[(uint64_t)f.b * T.stride + i]
-                                                     : T.acc[(uint64_t)f.b * T.stride + i];
-      if (f.null_mode == NULL_IF_COUNT_ZERO && cnt == 0) valid = false;
-      if (f.null_mode == NULL_IF_ACC_ALL_ONES && T.acc[(uint64_t)f.a * T.stride + i] == ~0ull) valid = false;
-      if (f.null_mode == NULL_IF_ACC_ZERO && T.acc[(uint64_t)f.a * T.stride + i] == 0ull) valid = false;
+  for (int o = 0; o < A.n_outs; ++o) {
+    const FinOut &f = A.outs[o];
+    uint64_t val[N];
+    bool valid[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      val[j] = 0;
+      valid[j] = occupied[j];
+      if (!occupied[j]) continue;
+      const uint64_t at = i[j];
+      unsigned long long cnt = f.cnt_src == CNT_ROWS  ? T.rowcnt[at]
+                               : f.cnt_src == CNT_NN ? T.nn[(uint64_t)f.b * T.stride + at]
+                                                     : T.acc[(uint64_t)f.b * T.stride + at];
+      if (f.null_mode == NULL_IF_COUNT_ZERO && cnt == 0) valid[j] = false;
+      if (f.null_mode == NULL_IF_ACC_ALL_ONES && T.acc[(uint64_t)f.a * T.stride + at] == ~0ull) valid[j] = false;
+      if (f.null_mode == NULL_IF_ACC_ZERO && T.acc[(uint64_t)f.a * T.stride + at] == 0ull) valid[j] = false;
       switch (f.kind) {
         case FIN_KEY: {
           uint64_t fm = f.bits >= 64 ? ~0ull : ((1ull << f.bits) - 1ull);
-          val = (k >> f.shift) & fm;
-          if (f.type == VT_I32) val = (uint64_t)(int64_t)(int32_t)(uint32_t)val;
+          val[j] = (k[j] >> f.shift) & fm;
+          if (f.type == VT_I32) val[j] = (uint64_t)(int64_t)(int32_t)(uint32_t)val[j];
           break;
         }
         case FIN_ACC_I64:
         case FIN_ACC_F64:
-          val = T.acc[(uint64_t)f.a * T.stride + i];
+          val[j] = T.acc[(uint64_t)f.a * T.stride + at];
           break;
         case FIN_ACC_ORD:
-          val = valid ? ord_inverse(T.acc[(uint64_t)f.a * T.stride + i], f.type) : 0;
+          val[j] = valid[j] ? ord_inverse(T.acc[(uint64_t)f.a * T.stride + at], f.type) : 0;
           break;
         case FIN_COUNT:
-          val = cnt;
+          val[j] = cnt;
           break;
         case FIN_AVG:
-          val = valid ? d2u(u2d(T.acc[(uint64_t)f.a * T.stride + i]) / (double)cnt) : 0;
+          val[j] = valid[j] ? d2u(u2d(T.acc[(uint64_t)f.a * T.stride + at]) / (double)cnt) : 0;
           break;
         case FIN_FIX_SUM:
-          val = d2u(fin_fix_sum(T, f, i));
+          val[j] = d2u(fin_fix_sum(T, f, at));
           break;
         case FIN_FIX_AVG:
-          val = valid ? d2u(fin_fix_sum(T, f, i) / (double)cnt) : 0;
+          val[j] = valid[j] ? d2u(fin_fix_sum(T, f, at) / (double)cnt) : 0;
           break;
         default:
           break;
       }
-      if (f.type == VT_I32)
-        ((uint32_t *)f.values)[pos] = (uint32_t)val;
-      else if (f.type == VT_BOOL) {
-        if (val & 1u) atomicOr((uint32_t *)f.values + (pos >> 5), 1u << (pos & 31u));
-      } else
-        ((uint64_t *)f.values)[pos] = val;
-      if (f.validity && valid) atomicOr(f.validity + (pos >> 5), 1u << (pos & 31u));
     }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      if (occupied[j]) {
+        if (f.type == VT_I32)
+          ((uint32_t *)f.values)[pos[j]] = (uint32_t)val[j];
+        else if (f.type == VT_BOOL) {
+          if (val[j] & 1u) atomicOr((uint32_t *)f.values + (pos[j] >> 5), 1u << (pos[j] & 31u));
+        } else
+          ((uint64_t *)f.values)[pos[j]] = val[j];
+      }
+      if (f.validity && occ[j] != 0) fin_store_validity(f.validity, occ[j], valid[j], first_pos[j]);
+    }
+  }
+}
+
+// Small tables: one atomic per wave is few enough, and no barriers.
+__global__ __launch_bounds__(256) void qe_finalize_small_kernel(const FinalizeArgs A) {
+  const AggTable &T = A.table;
+  if (A.overflow_sink && blockIdx.x == 0 && threadIdx.x == 0 && T.ctrl[1]) atomicAdd(A.overflow_sink, 1ull);
+  const uint64_t n_slots = T.cap + 1;
+  // (whole waves go round: the output code talks across lanes)
+  for (uint64_t i0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) & ~63ull; i0 < n_slots; i0 += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = i0 + lane_id();
+    unsigned long long k = i < n_slots ? T.keys[i] : AGG_EMPTY_KEY;
+    // output position: one atomic per wave for all its occupied slots, not one per slot
+    const bool occupied = k != AGG_EMPTY_KEY;
+    const uint64_t occ = __ballot(occupied);
+    if (occ == 0) continue;
+    unsigned long long wave_base = 0;
+    if (lane_id() == (uint32_t)__builtin_ctzll(occ)) wave_base = atomicAdd(A.out_count, (unsigned long long)__popcll(occ));
+    wave_base = readlane64(wave_base, __builtin_ctzll(occ));
+    if (i == T.cap) k = AGG_EMPTY_KEY;  // reserved slot holds the marker-valued key
+    fin_emit<1>(A, {i}, {k}, {occupied}, {occ}, {wave_base + mbcnt64(occ)}, {wave_base});
   }
 }
 
 // Output position of every occupied slot: one atomic per tile of 1024 slots (counts per wave and
 // item meet in LDS), not one per slot or per wave - a million groups would otherwise queue tens of
-// thousands of atomics on the one counter.
+// thousands of atomics on the one counter.  (Measured and not kept: one reservation per workgroup for a run of
+// tiles, counted in a pass of its own - fewer, longer workgroups, 0.21 -> 0.34 ms at a million groups; a lane's four
+// slots emitted together, loads first - more registers, 0.25 ms.  The kernel waits on dependent loads from a
+// sparsely occupied table, and many short workgroups hide that best.)
 constexpr int FIN_ITEMS = 4;
 
 __global__ __launch_bounds__(256) void qe_finalize_kernel(const FinalizeArgs A) {
@@ -747,62 +799,17 @@ __global__ __launch_bounds__(256) void qe_finalize_kernel(const FinalizeArgs A) 
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < FIN_ITEMS; ++j) {
+      if (occ[j] == 0) continue;
       const uint64_t i = tile + (uint64_t)j * 256 + threadIdx.x;
       unsigned long long k = key[j];
-      if (k == AGG_EMPTY_KEY) continue;
+      const bool occupied = k != AGG_EMPTY_KEY;
       uint32_t before = 0;
       for (int jj = 0; jj < FIN_ITEMS; ++jj)
         for (int w = 0; w < 4; ++w)
           if (jj < j || (jj == j && (uint32_t)w < wave)) before += s_count[jj][w];
       if (i == T.cap) k = AGG_EMPTY_KEY;  // reserved slot holds the marker-valued key
-      const unsigned long long pos = s_base + before + mbcnt64(occ[j]);
-      for (int o = 0; o < A.n_outs; ++o) {
-        const FinOut &f = A.outs[o];
-        uint64_t val = 0;
-        bool valid = true;
-        unsigned long long cnt = f.cnt_src == CNT_ROWS  ? T.rowcnt[i]
-                                 : f.cnt_src == CNT_NN ? T.nn[(uint64_t)f.b * T.stride + i]
-                                                       : T.acc[(uint64_t)f.b * T.stride + i];
-        if (f.null_mode == NULL_IF_COUNT_ZERO && cnt == 0) valid = false;
-        if (f.null_mode == NULL_IF_ACC_ALL_ONES && T.acc[(uint64_t)f.a * T.stride + i] == ~0ull) valid = false;
-        if (f.null_mode == NULL_IF_ACC_ZERO && T.acc[(uint64_t)f.a * T.stride + i] == 0ull) valid = false;
-        switch (f.kind) {
-          case FIN_KEY: {
-            uint64_t fm = f.bits >= 64 ? ~0ull : ((1ull << f.bits) - 1ull);
-            val = (k >> f.shift) & fm;
-            if (f.type == VT_I32) val = (uint64_t)(int64_t)(int32_t)(uint32_t)val;
-            break;
-          }
-          case FIN_ACC_I64:
-          case FIN_ACC_F64:
-            val = T.acc[(uint64_t)f.a * T.stride + i];
-            break;
-          case FIN_ACC_ORD:
-            val = valid ? ord_inverse(T.acc[(uint64_t)f.a * T.stride + i], f.type) : 0;
-            break;
-          case FIN_COUNT:
-            val = cnt;
-            break;
-          case FIN_AVG:
-            val = valid ? d2u(u2d(T.acc[(uint64_t)f.a * T.stride + i]) / (double)cnt) : 0;
-            break;
-          case FIN_FIX_SUM:
-            val = d2u(fin_fix_sum(T, f, i));
-            break;
-          case FIN_FIX_AVG:
-            val = valid ? d2u(fin_fix_sum(T, f, i) / (double)cnt) : 0;
-            break;
-          default:
-            break;
-        }
-        if (f.type == VT_I32)
-          ((uint32_t *)f.values)[pos] = (uint32_t)val;
-        else if (f.type == VT_BOOL) {
-          if (val & 1u) atomicOr((uint32_t *)f.values + (pos >> 5), 1u << (pos & 31u));
-        } else
-          ((uint64_t *)f.values)[pos] = val;
-        if (f.validity && valid) atomicOr(f.validity + (pos >> 5), 1u << (pos & 31u));
-      }
+      const unsigned long long first_pos = s_base + before;
+      fin_emit<1>(A, {i}, {k}, {occupied}, {occ[j]}, {first_pos + mbcnt64(occ[j])}, {first_pos});
     }
     __syncthreads();  // s_count / s_base are reused by the next tile
   }
