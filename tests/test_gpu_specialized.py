@@ -256,3 +256,23 @@ def test_mid_cardinality_large_batches(qe, ctx, groups, hint):
     sums = np.bincount(k, weights=v, minlength=groups)
     mags = np.bincount(k, weights=np.abs(v), minlength=groups)
     assert (np.abs(np.asarray(cols[1].values)[order] - sums[cnt > 0]) <= 1e-12 * mags[cnt > 0] + 1e-300).all()
+
+
+def test_null_outputs_of_a_large_table(qe, ctx):
+    """Groups whose aggregate is null (every input of the group null) among 200 K groups: the output routine of tables
+    beyond 64 K slots puts a wave's validity bits together before it writes them - rows valid and null mixed within a
+    wave, runs of rows that start anywhere in a 32-row validity word."""
+    n_keys = 200_000
+    r = rng(41)
+    k = np.tile(np.arange(n_keys, dtype=np.int64) * 7919 - 3, 3)
+    r.shuffle(k)
+    x = r.uniform(-10, 10, len(k))
+    null_group = ((k + 3) // 7919) % 3 == 0  # a third of the groups see nulls only
+    xv = ~null_group & (r.random(len(k)) > 0.2)
+    y = r.integers(-1000, 1000, len(k)).astype(np.int64)
+    yv = r.random(len(k)) > 0.6  # some groups lose all three of their rows by chance
+    cols = [orc.Array(orc.INT64, k), orc.Array(orc.FLOAT64, x, xv), orc.Array(orc.INT64, y, yv)]
+    aggs = [("sum", C(1)), ("min", C(1)), ("max", C(2)), ("avg", C(1)), ("count", C(2)), ("count", None)]
+    got, want = run_agg(qe, ctx, [cols], [C(0)], aggs, hint=n_keys, what="null outputs, 200 K groups")
+    sums = got[0].columns()[1]
+    assert sums.validity is not None and 0.3 < 1 - sums.validity.mean() < 0.4
