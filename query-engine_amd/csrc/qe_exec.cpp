@@ -126,11 +126,13 @@ static Column utf8_broadcast_column(Context *ctx, const std::string &s, int64_t 
   return c;
 }
 
-// Rows idx[0..m) of several utf8 columns.  The offsets of a group of columns are computed first, their byte totals come
-// back with one synchronisation, then the bytes are copied: the host waits once per group, not once per column.
+// Rows idx[0..m) of several utf8 columns.  The offsets of a group of (up to sixteen) columns are computed first, their byte
+// totals come back with one synchronisation, then the bytes are copied: the host waits once per group, not once per column.
 static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<const Column *> &srcs, const int64_t *idx, int64_t m) {
-  constexpr size_t GROUP = 6, FIRST_WORD = 64, CONTROL_WORDS = 8;  // a column's control block: ticket, byte total, look-back error, padding
-  static_assert(CONTROL_WORDS * sizeof(unsigned long long) == sizeof(FilterScratch), "control block");
+  // a column's control block: ticket, byte total, look-back error, one word of padding - the head of a FilterScratch,
+  // of which the offsets kernel touches nothing else
+  constexpr size_t GROUP = 16, FIRST_WORD = 64, CONTROL_WORDS = 4, CONTROL_BYTES = CONTROL_WORDS * sizeof(unsigned long long);
+  static_assert(offsetof(FilterScratch, error) + sizeof(unsigned long long) <= CONTROL_BYTES, "control block");
   std::vector<Column> out(srcs.size());
   ensure_counters(ctx);
   const size_t status_bytes = m > 0 ? (utf8_gather_offsets_status_bytes(m) + 63) / 64 * 64 : 0;
@@ -138,7 +140,7 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
     const size_t g1 = std::min(srcs.size(), g0 + GROUP), cols = g1 - g0;
     BufferPtr scratch;  // the group's control blocks, then its status arrays
     if (m > 0) {
-      const size_t sb = cols * (sizeof(FilterScratch) + status_bytes);
+      const size_t sb = (cols * CONTROL_BYTES + 63) / 64 * 64 + cols * status_bytes + sizeof(FilterScratch);
       scratch = device_buffer(ctx, sb);
       QE_HIP(hipMemsetAsync(scratch->ptr, 0, sb, ctx->stream));
     }
@@ -163,12 +165,12 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
       // lengths by row id, scanned into offsets, in one pass; offs[m] = the byte total
       ctx->prof_begin("qe_utf8_gather_offsets_kernel");
       QE_HIP(launch_utf8_gather_offsets(src.offsets_ptr(), src.validity_ptr(), idx, m, offs, c.validity ? (uint32_t *)c.validity->ptr : nullptr,
-                                        (char *)scratch->ptr + (j - g0) * sizeof(FilterScratch),
-                                        (char *)scratch->ptr + cols * sizeof(FilterScratch) + (j - g0) * status_bytes, ctx->dev.cus, ctx->stream));
+                                        (char *)scratch->ptr + (j - g0) * CONTROL_BYTES,
+                                        (char *)scratch->ptr + (cols * CONTROL_BYTES + 63) / 64 * 64 + (j - g0) * status_bytes, ctx->dev.cus, ctx->stream));
       ctx->prof_end();
     }
     if (m > 0) {
-      QE_HIP(hipMemcpyAsync(ctx->host_counters + FIRST_WORD, scratch->ptr, cols * sizeof(FilterScratch), hipMemcpyDeviceToHost, ctx->stream));
+      QE_HIP(hipMemcpyAsync(ctx->host_counters + FIRST_WORD, scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
       ctx->sync();  // (the scratch block is done with here too)
     }
     for (size_t j = g0; j < g1; ++j) {
