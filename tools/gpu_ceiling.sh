@@ -1,6 +1,8 @@
 #!/bin/bash
-# One session, one box: the read-stream ceiling probe (tools/experiments/stream_probe.hip, built to ab/stream_probe) and the
-# headline kernel (tools/probe.py c5), alternated, so that the kernel's rate can be put beside the ceiling of that session.
+# One session, one box: the read-stream ceiling probe and the headline kernel (tools/probe.py c5), alternated, so that
+# the kernel's rate can be put beside the ceiling of that session.  Build the probe first, here, where hipcc is:
+#   hipcc -O3 --offload-arch=gfx950 -o ab/stream_probe tools/experiments/stream_probe.hip
+# (ab/ is git-ignored and travels to the GPU box with the tree.)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/ceiling
