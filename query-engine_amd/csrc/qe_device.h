@@ -136,7 +136,9 @@ __device__ __forceinline__ bool utf8_equal(const uint8_t *a, const uint8_t *b, i
 // nothing else (a literal in memory costs a second load per byte compared).
 __device__ __forceinline__ uint32_t utf8_equals_lit16(const int32_t *offsets, const uint8_t *bytes, uint64_t lo, uint64_t hi, uint32_t len,
                                                     int64_t row0, uint32_t lane, uint32_t active) {
-  uint32_t eq = 0;
+  // rows whose length is the literal's, and where they start
+  uint32_t cand = 0;
+  int32_t at[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if ((active >> (2 * h)) & 3u) {
@@ -144,20 +146,58 @@ __device__ __forceinline__ uint32_t utf8_equals_lit16(const int32_t *offsets, co
       // offsets r, r + 1, r + 2: the two rows of the pair (the last one is only read when the second row exists)
       const int32_t o0 = offsets[r], o1 = offsets[r + 1];
       const int32_t o2 = ((active >> (2 * h + 1)) & 1u) ? offsets[r + 2] : o1;
+      if (((active >> (2 * h)) & 1u) && (uint32_t)(o1 - o0) == len) {
+        cand |= 1u << (2 * h);
+        at[2 * h] = o0;
+      }
+      if (((active >> (2 * h + 1)) & 1u) && (uint32_t)(o2 - o1) == len) {
+        cand |= 2u << (2 * h);
+        at[2 * h + 1] = o1;
+      }
+    }
+  }
+  if (len == 0 || __ballot(cand != 0) == 0) return cand;  // wave-uniform
+  // The candidates' bytes, all fetches of the lane's four rows in flight together.  A row that is no candidate reads
+  // the column's first bytes instead (at = 0): some row of the wave holds `len` bytes, so those exist.  From four
+  // bytes on a string is read as unaligned dwords at 0, 4, ... with the last one ending at its last byte - two
+  // fetches for "Female", never a byte outside the row.
+  uint32_t eq = cand;
+  if (len >= 4) {
+    uint32_t w[4][4];
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int32_t a0 = k ? o1 : o0, a1 = k ? o2 : o1;
-        bool same = ((active >> (2 * h + k)) & 1u) && (uint32_t)(a1 - a0) == len;
-        if (same) {
-          uint64_t w0 = 0, w1 = 0;
-          for (uint32_t i = 0; i < len; ++i) {  // uniform trip count
-            const uint64_t b = bytes[a0 + (int32_t)i];
-            if (i < 8) w0 |= b << (8 * i);
-            else w1 |= b << (8 * (i - 8));
-          }
-          same = w0 == lo && w1 == hi;
-        }
-        eq |= (same ? 1u : 0u) << (2 * h + k);
+    for (int i = 0; i < 4; ++i) {
+      if ((uint32_t)(4 * i) < len) {  // uniform
+        const uint32_t p = min((uint32_t)(4 * i), len - 4u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) __builtin_memcpy(&w[j][i], bytes + at[j] + (int32_t)p, 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if ((uint32_t)(4 * i) < len) {
+        const uint32_t p = min((uint32_t)(4 * i), len - 4u);  // bytes p .. p + 3 of the literal
+        uint64_t v = p < 8 ? lo >> (8 * p) : hi >> (8 * (p - 8));
+        if (p > 4 && p < 8) v |= hi << (64 - 8 * p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (w[j][i] != (uint32_t)v) eq &= ~(1u << j);
+      }
+    }
+  } else {
+    uint32_t b[4][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if ((uint32_t)i < len) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j][i] = bytes[at[j] + i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if ((uint32_t)i < len) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (b[j][i] != (uint32_t)((lo >> (8 * i)) & 0xffu)) eq &= ~(1u << j);
       }
     }
   }
@@ -849,6 +889,35 @@ __device__ __forceinline__ void store_compact(const VmOut &o, unsigned long long
       if (o.validity && ((s.valid >> j) & 1u)) atomicOr(o.validity + (pos >> 5), 1u << (pos & 31u));
     }
   }
+}
+
+// Validity bits of a wave-step's selected rows, which go to the consecutive output rows base .. base + cnt - 1 in rank
+// order.  The lanes drop their rows' bits as bytes at their ranks in `flags` (256 bytes of LDS owned by the wave), four
+// ballots over the bytes give the step's bits in output order, and nine lanes put them into the bitmap's words (zeroed
+// beforehand; neighbouring waves share the words at either end) - nine word-wide atomics a wave-step at most instead of
+// one per selected row.  Called by the whole wave.
+__device__ __forceinline__ void store_validity_ranked(uint32_t *validity, unsigned long long base, uint32_t sel, const uint32_t (&rank)[VM_R],
+                                                      uint32_t valid, uint8_t *flags, uint32_t cnt, uint32_t lane) {
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j)
+    if ((sel >> j) & 1u) flags[rank[j]] = (uint8_t)((valid >> j) & 1u);
+  uint64_t m[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t p = (uint32_t)k * 64u + lane;
+    m[k] = __ballot(p < cnt && flags[p] != 0);
+  }
+  if ((m[0] | m[1] | m[2] | m[3]) == 0) return;
+  uint32_t cur = 0, prev = 0;  // words `lane` and `lane - 1` of the 256 bits
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t w = (uint32_t)(m[i >> 1] >> (32 * (i & 1)));
+    cur = lane == (uint32_t)i ? w : cur;
+    prev = lane == (uint32_t)i + 1u ? w : prev;
+  }
+  const uint32_t sh = (uint32_t)(base & 31u);
+  const uint32_t word = sh ? (cur << sh) | (prev >> (32u - sh)) : cur;
+  if (lane < 9 && word != 0) atomicOr(validity + (base >> 5) + lane, word);
 }
 
 // --------------------------------------------------------- aggregate kernel

@@ -131,7 +131,7 @@ static Column utf8_broadcast_column(Context *ctx, const std::string &s, int64_t 
 static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<const Column *> &srcs, const int64_t *idx, int64_t m) {
   // a column's control block: ticket, byte total, look-back error, one word of padding - the head of a FilterScratch,
   // of which the offsets kernel touches nothing else
-  constexpr size_t GROUP = 16, FIRST_WORD = 64, CONTROL_WORDS = 4, CONTROL_BYTES = CONTROL_WORDS * sizeof(unsigned long long);
+  constexpr size_t GROUP = UTF8_GATHER_MAX_COLS, FIRST_WORD = 64, CONTROL_WORDS = 4, CONTROL_BYTES = CONTROL_WORDS * sizeof(unsigned long long);
   static_assert(offsetof(FilterScratch, error) + sizeof(unsigned long long) <= CONTROL_BYTES, "control block");
   std::vector<Column> out(srcs.size());
   ensure_counters(ctx);
@@ -144,6 +144,8 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
       scratch = device_buffer(ctx, sb);
       QE_HIP(hipMemsetAsync(scratch->ptr, 0, sb, ctx->stream));
     }
+    Utf8GatherCols launch{};
+    launch.n = (int)cols;
     for (size_t j = g0; j < g1; ++j) {
       const Column &src = *srcs[j];
       Column &c = out[j];
@@ -157,41 +159,41 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
         QE_HIP(hipMemsetAsync(c.validity->ptr, 0, bb, ctx->stream));
         c.null_count = -1;
       }
-      int32_t *offs = (int32_t *)c.offsets->ptr;
       if (m <= 0) {
-        QE_HIP(hipMemsetAsync(offs, 0, 4, ctx->stream));
+        QE_HIP(hipMemsetAsync(c.offsets->ptr, 0, 4, ctx->stream));
         continue;
       }
-      // lengths by row id, scanned into offsets, in one pass; offs[m] = the byte total
-      ctx->prof_begin("qe_utf8_gather_offsets_kernel");
-      QE_HIP(launch_utf8_gather_offsets(src.offsets_ptr(), src.validity_ptr(), idx, m, offs, c.validity ? (uint32_t *)c.validity->ptr : nullptr,
-                                        (char *)scratch->ptr + (j - g0) * CONTROL_BYTES,
-                                        (char *)scratch->ptr + (cols * CONTROL_BYTES + 63) / 64 * 64 + (j - g0) * status_bytes, ctx->dev.cus, ctx->stream));
-      ctx->prof_end();
+      Utf8GatherCol &g = launch.col[j - g0];
+      g.src_offsets = src.offsets_ptr();
+      g.src_validity = src.validity_ptr();
+      g.src_bytes = (const uint8_t *)src.values_ptr();
+      // (the source's bytes as its buffer bounds them: a 16-byte fetch of a short row must end inside)
+      g.src_total = src.values ? (int64_t)std::max<size_t>(src.values->bytes, (size_t)std::max<int64_t>(src.values_bytes, 0)) : 0;
+      g.out_offsets = (int32_t *)c.offsets->ptr;
+      g.out_validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
+      g.control = (char *)scratch->ptr + (j - g0) * CONTROL_BYTES;
+      g.status = (char *)scratch->ptr + (cols * CONTROL_BYTES + 63) / 64 * 64 + (j - g0) * status_bytes;
     }
-    if (m > 0) {
-      QE_HIP(hipMemcpyAsync(ctx->host_counters + FIRST_WORD, scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
-      ctx->sync();  // (the scratch block is done with here too)
-    }
+    if (m <= 0) continue;
+    // lengths by row id, scanned into offsets, in one pass over all columns of the group; offs[m] = a column's byte total
+    ctx->prof_begin("qe_utf8_gather_offsets_kernel");
+    QE_HIP(launch_utf8_gather_offsets(launch, idx, m, ctx->dev.cus, ctx->stream));
+    ctx->prof_end();
+    QE_HIP(hipMemcpyAsync(ctx->host_counters + FIRST_WORD, scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();  // (the scratch block is done with here too)
     for (size_t j = g0; j < g1; ++j) {
-      const Column &src = *srcs[j];
       Column &c = out[j];
-      int32_t total = 0;
-      if (m > 0) {
-        const unsigned long long *w = ctx->host_counters + FIRST_WORD + CONTROL_WORDS * (j - g0);
-        if (w[2] != 0) fail(QE_ERR_INTERNAL, "string gather look-back timed out");
-        if (w[1] > 2147483647ull) fail(QE_ERR_INVALID_ARGUMENT, "the selected strings of one column exceed 2^31 - 1 bytes: scan smaller batches");
-        total = (int32_t)w[1];
-      }
+      const unsigned long long *w = ctx->host_counters + FIRST_WORD + CONTROL_WORDS * (j - g0);
+      if (w[2] != 0) fail(QE_ERR_INTERNAL, "string gather look-back timed out");
+      if (w[1] > 2147483647ull) fail(QE_ERR_INVALID_ARGUMENT, "the selected strings of one column exceed 2^31 - 1 bytes: scan smaller batches");
+      const int32_t total = (int32_t)w[1];
       c.values_bytes = total;
       c.values = device_buffer(ctx, (size_t)total + 16);
-      ctx->prof_begin("qe_utf8_gather_bytes_kernel");
-      // (the source's bytes as its buffer bounds them: a 16-byte fetch of a short row must end inside)
-      const int64_t src_total = src.values ? (int64_t)std::max<size_t>(src.values->bytes, (size_t)std::max<int64_t>(src.values_bytes, 0)) : 0;
-      QE_HIP(launch_utf8_gather_bytes(src.offsets_ptr(), (const uint8_t *)src.values_ptr(), src_total, idx, m, (const int32_t *)c.offsets->ptr,
-                                      (uint8_t *)c.values->ptr, ctx->stream));
-      ctx->prof_end();
+      launch.col[j - g0].out_bytes = (uint8_t *)c.values->ptr;
     }
+    ctx->prof_begin("qe_utf8_gather_bytes_kernel");
+    QE_HIP(launch_utf8_gather_bytes(launch, idx, m, ctx->stream));
+    ctx->prof_end();
   }
   return out;
 }

@@ -62,14 +62,32 @@ hipError_t launch_fix_rescale(const AggTable &table, int acc, int delta, hipStre
 // utf8 helpers: gather rows `idx[0..m)` of a utf8 column.
 hipError_t launch_exclusive_scan_i32(int32_t *data, int64_t n, int32_t *block_sums, hipStream_t stream);
 size_t scan_scratch_elems(int64_t n);
-// Output offsets (out_offsets[0..m]) and validity bits of rows idx[0..m) of a string column in one launch.  control:
-// 64 zeroed bytes whose second word receives the byte total and whose third is non-zero if the look-back gave up;
-// status: utf8_gather_offsets_status_bytes(m) zeroed bytes.
+// Rows idx[0..m) of up to UTF8_GATHER_MAX_COLS string columns, every column in the same launch (a launch per column
+// leaves most of the chip idle while its first tiles start and its last ones end; the columns' tiles fill those gaps
+// for each other).  Per column: control = 32 zeroed bytes whose second word receives the byte total and whose third is
+// non-zero if the look-back gave up (the first column's first word is the launch's ticket counter); status =
+// utf8_gather_offsets_status_bytes(m) zeroed bytes.
+constexpr int UTF8_GATHER_MAX_COLS = 16;
+struct Utf8GatherCol {
+  const int32_t *src_offsets;
+  const uint8_t *src_validity;  // or nullptr
+  const uint8_t *src_bytes;
+  int64_t src_total;            // bytes of the source column as its buffer bounds them
+  int32_t *out_offsets;         // [m + 1], 16-byte aligned
+  uint32_t *out_validity;       // or nullptr
+  uint8_t *out_bytes;           // set before launch_utf8_gather_bytes
+  void *control;
+  void *status;
+};
+struct Utf8GatherCols {
+  Utf8GatherCol col[UTF8_GATHER_MAX_COLS];
+  int n;
+};
 size_t utf8_gather_offsets_status_bytes(int64_t m);
-hipError_t launch_utf8_gather_offsets(const int32_t *src_offsets, const uint8_t *src_validity, const int64_t *idx, int64_t m, int32_t *out_offsets,
-                                      uint32_t *out_validity, void *control, void *status, int cus, hipStream_t stream);
-hipError_t launch_utf8_gather_bytes(const int32_t *src_offsets, const uint8_t *src_bytes, int64_t src_total, const int64_t *idx, int64_t m,
-                                    const int32_t *dst_offsets, uint8_t *dst_bytes, hipStream_t stream);
+// out_offsets[0..m] and the validity bits of every column.
+hipError_t launch_utf8_gather_offsets(const Utf8GatherCols &cols, const int64_t *idx, int64_t m, int cus, hipStream_t stream);
+// The bytes, once out_offsets are there and out_bytes has been sized from the totals.
+hipError_t launch_utf8_gather_bytes(const Utf8GatherCols &cols, const int64_t *idx, int64_t m, hipStream_t stream);
 // Gather of strings by global row number over several source columns (group-by output keys).
 // Pass out_lengths to get the lengths (first pass), dst_offsets + dst_bytes to copy the bytes.
 struct Utf8Source {

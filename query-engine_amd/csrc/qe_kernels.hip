@@ -837,19 +837,28 @@ __global__ void qe_gather_rows_fixed_kernel(const FixedSource *sources, int n_so
 struct alignas(16) I32x4 { int32_t a, b, c, d; };
 constexpr int OFFSETS_THREADS = 1024, OFFSETS_TILE_MIN = 4096;  // (the status array is sized for the smallest tile)
 template <int R>  // rows a lane, consecutive: 4, 8 or 16 (measured: 4 and 8 alike, 16 much slower)
-__global__ __launch_bounds__(OFFSETS_THREADS) void qe_utf8_gather_offsets_kernel(const int32_t *src_offsets, const uint8_t *src_validity, const int64_t *idx,
-                                                                                   int64_t m, int64_t n_tiles, int32_t *out_offsets, uint32_t *out_validity,
-                                                                                   FilterScratch *scratch, unsigned long long *status) {
+__global__ __launch_bounds__(OFFSETS_THREADS) void qe_utf8_gather_offsets_kernel(const Utf8GatherCols C, const int64_t *idx, int64_t m, int64_t n_tiles) {
   constexpr int OFFSETS_TILE = OFFSETS_THREADS * R;
   constexpr uint32_t LANES_A_WORD = 32 / R;  // lanes whose rows share one 32-row validity word
   __shared__ int32_t s_wave[OFFSETS_THREADS / 64];
   __shared__ unsigned long long s_tile, s_base;
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  // One ticket = one tile of one column, the columns of a tile next to each other: a tile's predecessor in its column
+  // holds an earlier ticket, as the look-back needs, and the tile's row ids are read by all columns at about the same time.
+  FilterScratch *const tickets = (FilterScratch *)C.col[0].control;
   for (;;) {
-    if (threadIdx.x == 0) s_tile = atomicAdd(&scratch->ticket, 1ull);
+    if (threadIdx.x == 0) s_tile = atomicAdd(&tickets->ticket, 1ull);
     __syncthreads();
-    const int64_t tile = (int64_t)s_tile;
+    const int64_t ticket = (int64_t)s_tile;
+    const int64_t tile = ticket / C.n;
     if (tile >= n_tiles) break;
+    const Utf8GatherCol &col = C.col[ticket - tile * C.n];
+    const int32_t *const src_offsets = col.src_offsets;
+    const uint8_t *const src_validity = col.src_validity;
+    int32_t *const out_offsets = col.out_offsets;
+    uint32_t *const out_validity = src_validity ? col.out_validity : nullptr;
+    FilterScratch *const scratch = (FilterScratch *)col.control;
+    unsigned long long *const status = (unsigned long long *)col.status;
     const int64_t i0 = tile * OFFSETS_TILE + (int64_t)threadIdx.x * R;
     const bool whole = i0 + R <= m;
     int64_t r[R];
@@ -870,7 +879,9 @@ __global__ __launch_bounds__(OFFSETS_THREADS) void qe_utf8_gather_offsets_kernel
     for (int k = 0; k < R; ++k) {
       len[k] = 0;
       if (r[k] >= 0) {
-        len[k] = src_offsets[r[k] + 1] - src_offsets[r[k]];
+        int32_t two[2];  // offsets r and r + 1 in one (unaligned) 8-byte load
+        __builtin_memcpy(two, src_offsets + r[k], 8);
+        len[k] = two[1] - two[0];
         if (out_validity) bits |= ((src_validity[r[k] >> 3] >> (r[k] & 7)) & 1u) << k;
       }
       sum += len[k];
@@ -1010,10 +1021,14 @@ __device__ __forceinline__ uint32_t utf8_gather_dword(const int32_t *sd, const i
   return word;
 }
 
-// `src_total`: bytes of the source column (a 16-byte fetch must end inside them).
-__global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel(const int32_t *src_offsets, const uint8_t *__restrict__ src_bytes,
-                                                                                    int64_t src_total, const int64_t *idx, int64_t m,
-                                                                                    const int32_t *dst_offsets, uint8_t *__restrict__ dst_bytes) {
+// Column blockIdx.y of the launch.  (src_total, the bytes of the source column: a 16-byte fetch must end inside them.)
+__global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel(const Utf8GatherCols C, const int64_t *idx, int64_t m) {
+  const Utf8GatherCol &col = C.col[blockIdx.y];
+  const int32_t *const src_offsets = col.src_offsets;
+  const uint8_t *__restrict__ const src_bytes = col.src_bytes;
+  const int64_t src_total = col.src_total;
+  const int32_t *const dst_offsets = col.out_offsets;
+  uint8_t *__restrict__ const dst_bytes = col.out_bytes;
   __shared__ int32_t s_dst[GATHER_WAVES][65];
   __shared__ int32_t s_src[GATHER_WAVES][64];
   __shared__ __attribute__((aligned(16))) uint8_t s_stage[GATHER_WAVES][64 * GATHER_SHORT + 16];
@@ -1025,8 +1040,10 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel
     int32_t my_src = 0, my_dst = 0, my_len = 0;
     if (i < m) {
       const int64_t r = idx[i];
-      my_src = src_offsets[r];
-      my_len = src_offsets[r + 1] - my_src;
+      int32_t two[2];
+      __builtin_memcpy(two, src_offsets + r, 8);
+      my_src = two[0];
+      my_len = two[1] - two[0];
       my_dst = dst_offsets[i];
       s_src[wave][lane] = my_src;
       s_dst[wave][lane] = my_dst;
@@ -1047,9 +1064,18 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel
           uint32_t w[4];
           __builtin_memcpy(w, src_bytes + my_src + 16 * piece, 16);  // (any alignment: one 16-byte load)
           uint8_t *at = s_stage[wave] + (my_dst - a0) + 16 * piece;
+          // whole dwords as (unaligned) dword writes, the up to three bytes after them one by one: seven LDS
+          // instructions a piece at most, not sixteen
+          const int32_t here = left < 16 ? left : 16, full = here >> 2, tail = here & 3;
 #pragma unroll
-          for (int k = 0; k < 16; ++k)
-            if (k < left) at[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+          for (int q = 0; q < 4; ++q)
+            if (q < full) __builtin_memcpy(at + 4 * q, &w[q], 4);
+          if (tail) {
+            const uint32_t tw = full == 0 ? w[0] : full == 1 ? w[1] : full == 2 ? w[2] : w[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+              if (t < tail) at[4 * full + t] = (uint8_t)(tw >> (8 * t));
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1496,21 +1522,16 @@ hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream) {
 
 size_t utf8_gather_offsets_status_bytes(int64_t m) { return (size_t)((m + OFFSETS_TILE_MIN - 1) / OFFSETS_TILE_MIN) * sizeof(unsigned long long); }
 
-template <int R>
-static void launch_offsets(const int32_t *src_offsets, const uint8_t *src_validity, const int64_t *idx, int64_t m, int32_t *out_offsets,
-                           uint32_t *out_validity, void *control, void *status, int cus, hipStream_t stream) {
+hipError_t launch_utf8_gather_offsets(const Utf8GatherCols &cols, const int64_t *idx, int64_t m, int cus, hipStream_t stream) {
+  if (m <= 0 || cols.n <= 0) return hipSuccess;
+  if (cols.n > UTF8_GATHER_MAX_COLS || ((uintptr_t)idx & 15)) return hipErrorInvalidValue;
+  for (int i = 0; i < cols.n; ++i)
+    if ((uintptr_t)cols.col[i].out_offsets & 15) return hipErrorInvalidValue;
+  constexpr int R = 4;
   const int64_t tile = (int64_t)OFFSETS_THREADS * R, n_tiles = (m + tile - 1) / tile;
-  const int64_t resident = (int64_t)cus * 2;
-  const int grid = (int)(n_tiles < resident ? n_tiles : resident);
-  hipLaunchKernelGGL(qe_utf8_gather_offsets_kernel<R>, dim3(grid), dim3(OFFSETS_THREADS), 0, stream, src_offsets, src_validity, idx, m, n_tiles,
-                     out_offsets, src_validity ? out_validity : nullptr, (FilterScratch *)control, (unsigned long long *)status);
-}
-
-hipError_t launch_utf8_gather_offsets(const int32_t *src_offsets, const uint8_t *src_validity, const int64_t *idx, int64_t m, int32_t *out_offsets,
-                                      uint32_t *out_validity, void *control, void *status, int cus, hipStream_t stream) {
-  if (m <= 0) return hipSuccess;
-  if (((uintptr_t)idx | (uintptr_t)out_offsets) & 15) return hipErrorInvalidValue;
-  launch_offsets<4>(src_offsets, src_validity, idx, m, out_offsets, out_validity, control, status, cus, stream);
+  const int64_t tickets = n_tiles * cols.n, resident = (int64_t)cus * 2;
+  const int grid = (int)(tickets < resident ? tickets : resident);
+  hipLaunchKernelGGL(qe_utf8_gather_offsets_kernel<R>, dim3(grid), dim3(OFFSETS_THREADS), 0, stream, cols, idx, m, n_tiles);
   return hipGetLastError();
 }
 
@@ -1539,11 +1560,10 @@ hipError_t launch_exclusive_scan_i32(int32_t *data, int64_t n, int32_t *block_su
   return hipGetLastError();
 }
 
-hipError_t launch_utf8_gather_bytes(const int32_t *src_offsets, const uint8_t *src_bytes, int64_t src_total, const int64_t *idx, int64_t m,
-                                    const int32_t *dst_offsets, uint8_t *dst_bytes, hipStream_t stream) {
-  if (m <= 0) return hipSuccess;
-  hipLaunchKernelGGL(qe_utf8_gather_bytes_kernel, dim3(grid_for(m, 256, 8192)), dim3(GATHER_WAVES * 64), 0, stream, src_offsets,
-                     src_bytes, src_total, idx, m, dst_offsets, dst_bytes);
+hipError_t launch_utf8_gather_bytes(const Utf8GatherCols &cols, const int64_t *idx, int64_t m, hipStream_t stream) {
+  if (m <= 0 || cols.n <= 0) return hipSuccess;
+  if (cols.n > UTF8_GATHER_MAX_COLS) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(qe_utf8_gather_bytes_kernel, dim3(grid_for(m, 256, 8192), cols.n), dim3(GATHER_WAVES * 64), 0, stream, cols, idx, m);
   return hipGetLastError();
 }
 

@@ -222,7 +222,7 @@ __device__ __forceinline__ void filter_outs_static(const FilterArgs &A, const Ro
     VmOut o = A.outs[E];
     o.type = (uint8_t)Spec::out_type[E];
     if constexpr (Spec::out_nullable[E] == 0) o.validity = nullptr;
-    if constexpr (Spec::out_nullable[E] == 0 && (Spec::out_type[E] == VT_I64 || Spec::out_type[E] == VT_F64)) {
+    if constexpr (Spec::out_type[E] == VT_I64 || Spec::out_type[E] == VT_F64) {
 #pragma unroll
       for (int j = 0; j < VM_R; ++j)
         if ((sel >> j) & 1u) stage[rank[j]] = S[0].v[j];
@@ -239,6 +239,12 @@ __device__ __forceinline__ void filter_outs_static(const FilterArgs &A, const Ro
           out[i] = stage[i];
         }
       }
+      if constexpr (Spec::out_nullable[E] != 0) store_validity_ranked(o.validity, obase, sel, rank, S[0].valid, (uint8_t *)stage, cnt, c.lane);
+    } else if constexpr (Spec::out_type[E] == VT_I32 && Spec::out_nullable[E] != 0) {
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j)
+        if ((sel >> j) & 1u) ((uint32_t *)o.values)[obase + rank[j]] = (uint32_t)S[0].v[j];
+      store_validity_ranked(o.validity, obase, sel, rank, S[0].valid, (uint8_t *)stage, cnt, c.lane);
     } else {
       store_compact(o, obase, sel, rank, S[0]);
     }

@@ -52,6 +52,11 @@ def test_filter_and_aggregate_compiled(qe, jit_ctx):
     run_both(qe, jit_ctx, parts, chain, what="jit selection/projection chain")
     run_both(qe, jit_ctx, [cols], lambda m, scan: m.SelectionExec([scan], mk(m, ("gt", C(4), ("f64", 0.0)))), what="jit null predicate, all columns")
     assert any(k.startswith("qe_filter_jit<") for k in jit_kernels(jit_ctx))
+    # nullable outputs over many tiles: a wave's validity bits leave as whole words that neighbouring waves share, at
+    # every alignment (few, half and nearly all rows kept; a ragged last tile)
+    big = make_columns(300_017, seed=5)
+    for lim in (0.03, 0.5, 0.97):
+        run_both(qe, jit_ctx, [big], lambda m, scan: m.SelectionExec([scan], mk(m, ("lt", C(5), ("f64", lim)))), what=f"jit nullable outputs, {lim} kept")
     for n, n_keys in ((1, 1), (5000, 10), (70_000, 3000)):
         run_agg(qe, jit_ctx, [agg_columns(n, n_keys, seed=n + n_keys)], [C(0)], ALL_AGGS_F64, what=f"jit agg n={n} keys={n_keys}")
     acols = agg_columns(30_000, 40, seed=11, key_dtype=np.int32)
