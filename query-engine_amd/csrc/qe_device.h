@@ -873,24 +873,6 @@ __device__ __forceinline__ void rank_rows(uint32_t sel, uint32_t (&rank)[VM_R]) 
   rank[3] = c0 + lt1 + ((sel >> 2) & 1u);
 }
 
-__device__ __forceinline__ void store_compact(const VmOut &o, unsigned long long base, uint32_t sel,
-                                              const uint32_t (&rank)[VM_R], const Slot &s) {
-#pragma unroll
-  for (int j = 0; j < VM_R; ++j) {
-    if ((sel >> j) & 1u) {
-      unsigned long long pos = base + rank[j];
-      if (o.type == VT_BOOL) {
-        if (s.v[j] & 1u) atomicOr((uint32_t *)o.values + (pos >> 5), 1u << (pos & 31u));
-      } else if (o.type == VT_I32) {
-        ((uint32_t *)o.values)[pos] = (uint32_t)s.v[j];
-      } else {
-        ((uint64_t *)o.values)[pos] = s.v[j];
-      }
-      if (o.validity && ((s.valid >> j) & 1u)) atomicOr(o.validity + (pos >> 5), 1u << (pos & 31u));
-    }
-  }
-}
-
 // Validity bits of a wave-step's selected rows, which go to the consecutive output rows base .. base + cnt - 1 in rank
 // order.  The lanes drop their rows' bits as bytes at their ranks in `flags` (256 bytes of LDS owned by the wave), four
 // ballots over the bytes give the step's bits in output order, and nine lanes put them into the bitmap's words (zeroed
@@ -901,6 +883,8 @@ __device__ __forceinline__ void store_validity_ranked(uint32_t *validity, unsign
 #pragma unroll
   for (int j = 0; j < VM_R; ++j)
     if ((sel >> j) & 1u) flags[rank[j]] = (uint8_t)((valid >> j) & 1u);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's own LDS writes, before its reads below
+  __builtin_amdgcn_wave_barrier();
   uint64_t m[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -918,6 +902,27 @@ __device__ __forceinline__ void store_validity_ranked(uint32_t *validity, unsign
   const uint32_t sh = (uint32_t)(base & 31u);
   const uint32_t word = sh ? (cur << sh) | (prev >> (32u - sh)) : cur;
   if (lane < 9 && word != 0) atomicOr(validity + (base >> 5) + lane, word);
+}
+
+// store_compact with the bit-packed parts - validity, boolean values - assembled by the wave (store_validity_ranked)
+// instead of one atomic per row.  Called by the whole wave; `cnt` = the wave-step's selected rows.
+__device__ __forceinline__ void store_compact_ranked(const VmOut &o, unsigned long long base, uint32_t sel, const uint32_t (&rank)[VM_R],
+                                                     const Slot &s, uint8_t *flags, uint32_t cnt, uint32_t lane) {
+  if (o.type == VT_BOOL) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) bits |= (uint32_t)(s.v[j] & 1u) << j;
+    store_validity_ranked((uint32_t *)o.values, base, sel, rank, bits, flags, cnt, lane);
+  } else {
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) {
+      if ((sel >> j) & 1u) {
+        if (o.type == VT_I32) ((uint32_t *)o.values)[base + rank[j]] = (uint32_t)s.v[j];
+        else ((uint64_t *)o.values)[base + rank[j]] = s.v[j];
+      }
+    }
+  }
+  if (o.validity) store_validity_ranked(o.validity, base, sel, rank, s.valid, flags, cnt, lane);
 }
 
 // --------------------------------------------------------- aggregate kernel

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, FULL ? 2 : 3) void qe_filter_kern
   __shared__ unsigned long long s_tile;
   __shared__ unsigned long long s_base;
   __shared__ uint32_t s_cnt[FILTER_STEPS * VM_BLOCK_WAVES];
+  __shared__ uint8_t s_flags[VM_BLOCK_WAVES][VM_WAVE_ROWS];  // a wave's validity / boolean bits on their way out
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   const int64_t n = A.n_rows;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, FULL ? 2 : 3) void qe_filter_kern
           Slot S[VM_MAX_DEPTH];
           vm_eval<FULL>(A.prog, R, phase2 ? A.outs[e].pc : A.pred_pc, c, K, S);
           if (phase2)
-            store_compact(A.outs[e], obase, c.active, rank, S[0]);
+            store_compact_ranked(A.outs[e], obase, c.active, rank, S[0], s_flags[wave], s_cnt[s * VM_BLOCK_WAVES + wave], lane);
           else
             sel = c.active & S[0].valid & bool_bits(S[0]);
         }

@@ -240,13 +240,8 @@ __device__ __forceinline__ void filter_outs_static(const FilterArgs &A, const Ro
         }
       }
       if constexpr (Spec::out_nullable[E] != 0) store_validity_ranked(o.validity, obase, sel, rank, S[0].valid, (uint8_t *)stage, cnt, c.lane);
-    } else if constexpr (Spec::out_type[E] == VT_I32 && Spec::out_nullable[E] != 0) {
-#pragma unroll
-      for (int j = 0; j < VM_R; ++j)
-        if ((sel >> j) & 1u) ((uint32_t *)o.values)[obase + rank[j]] = (uint32_t)S[0].v[j];
-      store_validity_ranked(o.validity, obase, sel, rank, S[0].valid, (uint8_t *)stage, cnt, c.lane);
     } else {
-      store_compact(o, obase, sel, rank, S[0]);
+      store_compact_ranked(o, obase, sel, rank, S[0], (uint8_t *)stage, cnt, c.lane);
     }
     filter_outs_static<Spec, E + 1>(A, c, K, obase, sel, rank, stage, cnt);
   }
