@@ -953,6 +953,8 @@ struct LdsTable {
   uint32_t cap;
   uint32_t stride;           // cap + 1
   uint32_t limit;
+  uint32_t home_mask;        // hash -> first slot of a key's probe sequence: cap - 1, or (cap - 1) & ~1 in a table that is
+                             // also probed a pair of slots at a time (both walks then meet the slots in the same order)
 };
 
 // COUNT_HERE: a claimed slot is counted into the table's group counter on the spot.  Callers that claim many slots at
@@ -1032,7 +1034,7 @@ __device__ __forceinline__ int32_t lds_find_or_claim(const LdsTable &L, uint64_t
     (void)atomicCAS(&L.keys[L.cap], AGG_EMPTY_KEY, 0ull);
     return (int32_t)L.cap;
   }
-  uint32_t s = hash32(key) & (L.cap - 1);
+  uint32_t s = hash32(key) & L.home_mask;
 #pragma unroll 1
   for (int p = 0; p < LDS_MAX_PROBE; ++p) {
     unsigned long long cur = *(volatile unsigned long long *)&L.keys[s];
@@ -1066,7 +1068,7 @@ __device__ __forceinline__ void lds_find_or_claim4(const LdsTable &L, const uint
   uint32_t open = rows;  // rows still looking
 #pragma unroll
   for (int j = 0; j < VM_R; ++j) {
-    h[j] = hash32(key[j]) & mask;
+    h[j] = hash32(key[j]) & L.home_mask;
     slot[j] = ((rows >> j) & 1u) ? SLOT_LDS_MISS : SLOT_NONE;
     if (((rows >> j) & 1u) && key[j] == AGG_EMPTY_KEY) {
       // the one key equal to the empty marker lives in the reserved slot
@@ -1264,6 +1266,7 @@ __device__ __forceinline__ void agg_lds_setup(LdsTable &L, unsigned long long *l
   L.cap = lds_cap;
   L.stride = lds_cap + 1;
   L.limit = lds_limit;
+  L.home_mask = lds_cap - 1;
   L.keys = lds_raw;
   L.acc = L.keys + L.stride;
   L.rowcnt = (uint32_t *)(L.acc + (size_t)n_accs * L.stride);

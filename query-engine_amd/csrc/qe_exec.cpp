@@ -544,7 +544,8 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
     for (size_t j = 0; j < utf8_cols.size(); ++j) out.cols[utf8_cols[j]] = std::move(got[j]);
   }
   for (int i : utf8_lits) out.cols[i] = utf8_broadcast_column(ctx, outs[i]->sval, m);
-  if (need_rowid) ctx->sync();  // rowid buffer goes back to the pool on return
+  // (the row ids go back to the pool on return with the byte copies still reading them: the pool hands a block out
+  // again only to work queued later on this stream; the host is free to prepare the next batch meanwhile)
   return out;
 }
 

@@ -482,13 +482,14 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_kernel(const Sc
 // One ticket = one partition: all its rows folded into a fresh LDS table, the table flushed into
 // the global one.  A partition holds (groups / partitions) distinct keys, chosen by the host to fit.
 __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(const PartArgs A) {
-  extern __shared__ unsigned long long lds_raw[];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lds_raw[];  // (the key slots are read in pairs)
   __shared__ unsigned long long s_ticket;
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t n_waves = blockDim.x >> 6;
   LdsTable L;
   agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, A.n_accs, false);
+  L.home_mask = (A.lds_cap - 1) & ~1u;  // whole steps probe pairs of slots, the rest one slot at a time: one order for both
   SpillState none;
   none.keys = nullptr;
   none.vals = nullptr;
@@ -550,7 +551,12 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
 #pragma unroll
           for (int j = 0; j < VM_R; ++j) slot[j] = (int32_t)(hash32(G.key[j]) & (L.cap - 1));
         } else {
-          lds_find_or_claim4(L, G.key, 0xFu, LDS_MAX_PROBE, slot);
+          // a pair of slots a probe (one 16-byte LDS read): half the dependent round trips of the longest probe
+          // sequence among the wave's 256 rows, which is what a step waits for
+          uint32_t slot8[VM_R];
+          const uint32_t hit = lds_pair_find_or_claim4<false>(L, G.key, 0xFu, LDS_MAX_PROBE / 2, slot8);
+#pragma unroll
+          for (int j = 0; j < VM_R; ++j) slot[j] = ((hit >> j) & 1u) ? (int32_t)(slot8[j] >> 3) : SLOT_LDS_MISS;
         }
         if (__ballot((slot[0] | slot[1] | slot[2] | slot[3]) < 0) == 0) {
           if (A.ablate & 2) continue;
