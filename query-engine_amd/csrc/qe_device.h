@@ -957,6 +957,25 @@ struct LdsTable {
                              // also probed a pair of slots at a time (both walks then meet the slots in the same order)
 };
 
+// Cheap 32-bit hash: its low bits name a key's slot in an LDS table, its top bits the key's partition in the many-groups
+// mode and its home slot in the global table.
+__device__ __forceinline__ uint32_t hash32(uint64_t key) {
+  uint32_t h = (uint32_t)key * 0x9E3779B1u ^ (uint32_t)(key >> 32) * 0x85EBCA77u;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 13;
+  return h;
+}
+
+// Home slot of a key in the global table = the top bits of the 32-bit hash whose top bits also name the key's partition
+// in the many-groups mode (below them, bits of `h` in a table of more than 2^32 slots): the keys of one partition live
+// in one stretch of the table, which a partition's flush then walks instead of touching lines all over it.
+__device__ __forceinline__ uint64_t global_home(const AggTable &T, uint64_t key, uint64_t h) {
+  const int lg = 63 - __builtin_clzll(T.cap);
+  const uint64_t s = lg <= 32 ? (uint64_t)(hash32(key) >> 1 >> (31 - lg)) : (((uint64_t)hash32(key) << (lg - 32)) | ((h >> 20) & ((1ull << (lg - 32)) - 1ull)));
+  return s & (T.cap - 1);
+}
+
 // COUNT_HERE: a claimed slot is counted into the table's group counter on the spot.  Callers that claim many slots at
 // once (a workgroup flushing its LDS table) pass false, take `claimed` and add the wave's total with one atomic: a
 // million claims are otherwise a million atomics on one word.
@@ -972,8 +991,8 @@ __device__ __forceinline__ int64_t global_find_or_claim(const AggTable &T, uint6
     }
     return (int64_t)T.cap;
   }
-  uint64_t mask = T.cap - 1;
-  uint64_t s = (h >> 20) & mask;
+  const uint64_t mask = T.cap - 1;
+  uint64_t s = global_home(T, key, h);
 #pragma unroll 1
   for (uint64_t p = 0; p <= mask; ++p) {
     unsigned long long cur = __hip_atomic_load(&T.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1014,15 +1033,6 @@ __device__ __forceinline__ bool table_given_up(const AggTable &T, GiveUpWatch &w
   const bool lost = __builtin_amdgcn_readfirstlane((int)(w.seen != 0)) != 0;
   if ((w.steps++ & 63u) == 63u) w.seen = __hip_atomic_load(&T.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return lost;
-}
-
-// Cheap 32-bit hash for the LDS table (the global table uses the full mix64).
-__device__ __forceinline__ uint32_t hash32(uint64_t key) {
-  uint32_t h = (uint32_t)key * 0x9E3779B1u ^ (uint32_t)(key >> 32) * 0x85EBCA77u;
-  h ^= h >> 15;
-  h *= 0x2C1B3C6Du;
-  h ^= h >> 13;
-  return h;
 }
 
 // LDS slot of `key` (claiming one if new), or -1 when the key does not fit the LDS table.
@@ -1507,9 +1517,140 @@ __device__ __forceinline__ void agg_fold(const LdsTable &L, const AggTable &T, u
 // EXCLUSIVE: no other workgroup of the launch holds any of this table's keys (the partition-wise aggregate: partitions
 // share no key) - a group's row in the global table is then read, combined and stored plainly, and a group claimed
 // just now is only stored; slots are still claimed by compare-and-swap (keys of different partitions meet in the table).
+// Up to FLUSH_BATCH slots a thread at once when the table is at most that many times the workgroup wide and has at most
+// FLUSH_BATCH_ACCS accumulators without validity counts (the wide workgroups of the many-groups mode): the key probes of
+// all the thread's slots are in flight together, then the reads of every group's row, then the stores.  One slot after
+// the other, accumulator by accumulator, a flush is a chain of some twenty-five dependent trips to memory - it measured
+// 40 to 130 microseconds a partition, a fifth of the partition pass.
+constexpr int FLUSH_BATCH = 5, FLUSH_BATCH_ACCS = 4, FLUSH_BATCH_PROBES = 6;
+
+template <bool EXCLUSIVE>
+__device__ __forceinline__ void agg_flush_batched(const LdsTable &L, const AggTable &T, const VmAcc *accs, int n_accs) {
+  unsigned long long k[FLUSH_BATCH];
+  uint64_t at[FLUSH_BATCH];
+  long long g[FLUSH_BATCH];
+  uint32_t live = 0, open = 0, claimed = 0;
+#pragma unroll
+  for (int r = 0; r < FLUSH_BATCH; ++r) {
+    const uint32_t i = (uint32_t)r * blockDim.x + threadIdx.x;
+    bool on = i < L.stride;
+    k[r] = on ? L.keys[i] : AGG_EMPTY_KEY;
+    if (on && i == L.cap) {
+      // the reserved slot: the key equal to the empty marker, if it came (its home is the global table's reserved slot)
+      on = k[r] != AGG_EMPTY_KEY;
+      k[r] = AGG_EMPTY_KEY;
+      g[r] = -1;
+      if (on) {
+        bool c = false;
+        g[r] = global_find_or_claim<false>(T, AGG_EMPTY_KEY, 0, &c);
+        claimed |= c ? 1u << r : 0u;
+        live |= g[r] >= 0 ? 1u << r : 0u;
+      }
+      at[r] = 0;
+      continue;
+    }
+    on = on && k[r] != AGG_EMPTY_KEY;
+    g[r] = -1;
+    at[r] = on ? global_home(T, k[r], mix64(k[r])) : 0;
+    open |= on ? 1u << r : 0u;
+  }
+  const uint64_t mask = T.cap - 1;
+#pragma unroll 1
+  for (int probe = 0; probe < FLUSH_BATCH_PROBES && open != 0; ++probe) {
+    unsigned long long cur[FLUSH_BATCH];
+#pragma unroll
+    for (int r = 0; r < FLUSH_BATCH; ++r) cur[r] = ((open >> r) & 1u) ? __hip_atomic_load(&T.keys[at[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    uint32_t want = 0;
+#pragma unroll
+    for (int r = 0; r < FLUSH_BATCH; ++r) want |= (((open >> r) & 1u) && cur[r] == AGG_EMPTY_KEY) ? 1u << r : 0u;
+#pragma unroll
+    for (int r = 0; r < FLUSH_BATCH; ++r)
+      if ((want >> r) & 1u) cur[r] = atomicCAS(&T.keys[at[r]], AGG_EMPTY_KEY, k[r]);  // (the old value: empty = the slot is ours)
+#pragma unroll
+    for (int r = 0; r < FLUSH_BATCH; ++r) {
+      const bool o = ((open >> r) & 1u) != 0, w = ((want >> r) & 1u) != 0;
+      const bool ours = o && w && cur[r] == AGG_EMPTY_KEY;
+      const bool found = o && (ours || cur[r] == k[r]);
+      claimed |= ours ? 1u << r : 0u;
+      live |= found ? 1u << r : 0u;
+      g[r] = found ? (long long)at[r] : g[r];
+      open &= found ? ~(1u << r) : ~0u;
+      at[r] = (o && !found) ? ((at[r] + 1) & mask) : at[r];
+    }
+  }
+  if (open != 0) {
+    // a long probe sequence: the general walk, which also knows when to give the table up
+#pragma unroll
+    for (int r = 0; r < FLUSH_BATCH; ++r) {
+      if ((open >> r) & 1u) {
+        bool c = false;
+        g[r] = global_find_or_claim<false>(T, k[r], mix64(k[r]), &c);
+        claimed |= c ? 1u << r : 0u;
+        live |= g[r] >= 0 ? 1u << r : 0u;
+      }
+    }
+  }
+  {
+    const uint32_t fresh = (uint32_t)__popc(claimed);
+    const unsigned long long total = wave_sum_u64(fresh);
+    if (lane_id() == 0 && total != 0) atomicAdd(&T.ctrl[0], total);
+  }
+  if (live == 0) return;
+  if (EXCLUSIVE) {
+    // nobody else touches these groups: read the rows of all of them, combine, store
+    unsigned long long row[FLUSH_BATCH], val[FLUSH_BATCH][FLUSH_BATCH_ACCS];
+#pragma unroll
+    for (int r = 0; r < FLUSH_BATCH; ++r) {
+      const bool old = ((live >> r) & 1u) && !((claimed >> r) & 1u);
+      row[r] = old ? T.rowcnt[g[r]] : 0ull;
+#pragma unroll
+      for (int a = 0; a < FLUSH_BATCH_ACCS; ++a) val[r][a] = (a < n_accs && old) ? T.acc[(uint64_t)a * T.stride + g[r]] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < FLUSH_BATCH; ++r) {
+      if (!((live >> r) & 1u)) continue;
+      const uint32_t i = (uint32_t)r * blockDim.x + threadIdx.x;
+      const bool fresh = ((claimed >> r) & 1u) != 0;
+      T.rowcnt[g[r]] = row[r] + L.rowcnt[i];
+#pragma unroll
+      for (int a = 0; a < FLUSH_BATCH_ACCS; ++a) {
+        if (a < n_accs) {
+          const uint32_t op = accs[a].op;
+          T.acc[(uint64_t)a * T.stride + g[r]] = acc_combine(op, fresh ? acc_identity(op) : val[r][a], L.acc[a * L.stride + i]);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < FLUSH_BATCH; ++r) {
+      if (!((live >> r) & 1u)) continue;
+      const uint32_t i = (uint32_t)r * blockDim.x + threadIdx.x;
+      const uint32_t rc = L.rowcnt[i];
+      if (rc) atomicAdd(&T.rowcnt[g[r]], (unsigned long long)rc);
+#pragma unroll
+      for (int a = 0; a < FLUSH_BATCH_ACCS; ++a) {
+        if (a < n_accs) {
+          const uint32_t op = accs[a].op;
+          const unsigned long long v = L.acc[a * L.stride + i];
+          unsigned long long *dst = &T.acc[(uint64_t)a * T.stride + g[r]];
+          if (v != acc_identity(op) || op == ACC_SUM_F64) {
+            if (op == ACC_MIN) atomicMin(dst, v);
+            else if (op == ACC_MAX) atomicMax(dst, v);
+            else acc_apply(dst, op, v);
+          }
+        }
+      }
+    }
+  }
+}
+
 template <bool EXCLUSIVE = false>
 __device__ __forceinline__ void agg_flush(const LdsTable &L, const AggTable &T, const VmAcc *accs, int n_accs) {
   __syncthreads();
+  if (L.nn == nullptr && n_accs <= FLUSH_BATCH_ACCS && L.stride <= (uint32_t)FLUSH_BATCH * blockDim.x) {
+    agg_flush_batched<EXCLUSIVE>(L, T, accs, n_accs);
+    return;
+  }
   const uint32_t rounds = (L.stride + blockDim.x - 1) / blockDim.x;
   for (uint32_t r = 0; r < rounds; ++r) {
     const uint32_t i = r * blockDim.x + threadIdx.x;

@@ -484,9 +484,8 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_kernel(const Sc
 __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(const PartArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long lds_raw[];  // (the key slots are read in pairs)
   __shared__ unsigned long long s_ticket;
+  __shared__ uint32_t s_step;  // the current partition's next step of 256 rows that no wave has taken yet
   const uint32_t lane = lane_id();
-  const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t n_waves = blockDim.x >> 6;
   LdsTable L;
   agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, A.n_accs, false);
   L.home_mask = (A.lds_cap - 1) & ~1u;  // whole steps probe pairs of slots, the rest one slot at a time: one order for both
@@ -500,6 +499,7 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
     __syncthreads();
     if (threadIdx.x == 0) {
       s_ticket = atomicAdd(A.ticket, 1ull);
+      s_step = 0;
       // a global table that has been given up (the host starts over with a larger one): no further partition
       if (__hip_atomic_load(&A.table.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) s_ticket = (unsigned long long)A.n_parts;
     }
@@ -511,7 +511,8 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
     const int64_t end = p + 1 < A.n_parts ? (int64_t)A.offsets[(p + 1) * A.stride] : A.total;
     // The keys and the first value column of a wave's next 256 rows are loaded while it works on the current ones:
     // the work is LDS round trips, one after the other, and a memory round trip on top of every step's would double it.
-    const int64_t stride_rows = (int64_t)n_waves * VM_WAVE_ROWS;
+    // Steps are taken from a counter, not dealt out in turn: the sixteen waves do not run at one pace (the oldest wave
+    // of a SIMD is served first; dealt equal shares, wave 0 stood a fifth of a partition's time at the barrier).
     unsigned long long nkey[VM_R], nval[VM_R];
     auto fetch = [&](int64_t r0) {
 #pragma unroll
@@ -525,9 +526,14 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
         }
       }
     };
-    int64_t r0 = start + (int64_t)wave * VM_WAVE_ROWS;
+    auto take = [&]() -> int64_t {
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(&s_step, 1u);
+      return start + (int64_t)__builtin_amdgcn_readfirstlane((int)t) * VM_WAVE_ROWS;
+    };
+    int64_t r0 = take(), rn = 0;
     if (r0 < end) fetch(r0);
-    for (; r0 < end; r0 += stride_rows) {
+    for (; r0 < end; r0 = rn) {
       if (table_given_up(A.table, watch)) break;
       AggRows G;
       Slot in;
@@ -540,7 +546,8 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
         G.slot[j] = SLOT_NONE;
         if (r0 + j * 64 + lane < end) active |= 1u << j;
       }
-      if (r0 + stride_rows < end) fetch(r0 + stride_rows);
+      rn = take();
+      if (rn < end) fetch(rn);
       // The common step: 256 rows, every one of which finds (or claims) a slot in the LDS table - by construction a
       // partition's keys fit it.  No per-row bookkeeping of who goes where: four lookups, then one LDS operation per
       // row and accumulator.  Anything else (the partition's last rows, a key the table has no room for) takes the
