@@ -645,3 +645,24 @@ def test_string_gather_over_more_tiles_than_workgroups(qe, ctx):
     cols = [orc.Array(orc.INT32, flag), with_nulls, without]
     got, want = run_both(qe, ctx, [cols], lambda m, scan: m.SelectionExec([scan], mk(m, ("eq", C(0), ("i32", 1)))), what="string gather, 2.6 M rows")
     assert got[0].num_rows == int(flag.sum()) > 512 * 4096
+
+
+def test_string_gather_over_more_columns_than_one_launch(qe, ctx):
+    """Nineteen string columns through one Selection: the gather kernels take up to sixteen columns a launch, so this
+    is two launches of each; the columns differ (lengths, nulls or none, one all empty, one with long rows), share the
+    selection's row ids, and a tile's tickets interleave them.  Also a selection that keeps nothing."""
+    n = 150_011
+    r = np.random.default_rng(31)
+    flag = (r.random(n) < 0.4).astype(np.int32)
+    cols = [orc.Array(orc.INT32, flag), orc.Array(orc.FLOAT64, r.uniform(0, 1, n), r.random(n) > 0.2)]
+    for j in range(19):
+        top = [0, 1, 7, 16, 17, 40, 64, 65, 200][j % 9] if j != 5 else 0
+        lens = r.integers(0, top + 1, n).astype(np.int64)
+        offs = np.zeros(n + 1, np.int32)
+        np.cumsum(lens, out=offs[1:])
+        data = r.integers(32, 127, int(offs[-1]) + 1).astype(np.uint8)[: int(offs[-1])]
+        cols.append(orc.Array(orc.UTF8, (offs, data), (r.random(n) > 0.15) if j % 3 else None))
+    got, want = run_both(qe, ctx, [cols], lambda m, scan: m.SelectionExec([scan], mk(m, ("eq", C(0), ("i32", 1)))), what="19 string columns")
+    assert got[0].num_rows == int(flag.sum()) and got[0].num_columns == 21
+    got, want = run_both(qe, ctx, [cols], lambda m, scan: m.SelectionExec([scan], mk(m, ("eq", C(0), ("i32", 7)))), what="19 string columns, nothing kept")
+    assert got[0].num_rows == 0
