@@ -1386,6 +1386,8 @@ hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipSt
     const bool many_groups = args.spill.keys != nullptr && (args.tune & 2u) != 0;
     static int no_flush = tuned("QE_SPILL_ABLATE_FLUSH", 0);
     if (no_flush) args.tune |= 4u;
+    static int prio = tuned("QE_SPILL_PRIO", 1);
+    if (prio) args.tune |= 8u;  // (bit 3: the waves of a SIMD take the high priority in turn)
     const bool spill_kernel = lean != 2 && many_groups;
     if (many_groups && !spill_kernel) args.tune |= 1u;  // (with many groups the hot keys cost more than they save: 2.67 -> 2.42 ms per 256 M rows)
     // the first pass counts its logged rows per partition when the caller asked for it (args.cells), the launch has one

@@ -886,7 +886,19 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_spill_static
   agg_lds_clear(L, A.accs, Spec::n_accs);  // ends with a barrier
   SpillState sp = spill_begin(A.spill, wave);
   const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
+  uint32_t turn = wave >> 2;  // (waves 4 apart share a SIMD)
   for (int64_t ws = (int64_t)blockIdx.x * n_waves + wave; ws < nsteps; ws += (int64_t)gridDim.x * n_waves) {
+    if (A.tune & 8u) {
+      // The four waves of a SIMD take the high priority in turn, a step each.  Left alone the oldest wave is served
+      // first whenever several are ready, the waves drift apart, and the last ones finish alone (first pass of C4:
+      // 1.44 -> 1.41 ms; a fixed order the other way round, youngest first: 1.50).
+      switch (turn++ & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        case 2: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+      }
+    }
     RowCtx c;
     c.row0 = ws * VM_WAVE_ROWS;
     c.n = n;
