@@ -314,7 +314,12 @@ void qe_plan_free(qe_plan *plan);
  * (physical_plan/mod.rs:58-65).  Consumes the plan. */
 qe_status qe_plan_execute(qe_plan *plan, qe_iter **out);
 /* Iterator::next: QE_OK with a batch, QE_END when exhausted, or an error.
- * Output batches are device resident and owned by the caller. */
+ * Output batches are device resident and owned by the caller.  Their row
+ * count is final on return; their buffers are complete in the order of the
+ * context's stream (a projection's values, a selection's string bytes may
+ * still be on their way): work queued on that stream afterwards, the next
+ * operator and qe_batch_to_host see them whole, a caller that reads them from
+ * another stream or maps them to the host calls qe_context_synchronize first. */
 qe_status qe_iter_next(qe_iter *iter, qe_batch **out);
 void qe_iter_free(qe_iter *iter);
 
