@@ -700,18 +700,32 @@ __device__ __forceinline__ void fin_emit(const FinalizeArgs &A, const uint64_t (
     const FinOut &f = A.outs[o];
     uint64_t val[N];
     bool valid[N];
+    // What the output reads of a group's row - a count, an accumulator - for all N items before anything is computed
+    // or stored, with no branch between the loads (which arrays they come from is the same for every lane): the N
+    // items' trips to memory overlap.  One item after the other, each behind the switch below, an output column was
+    // N dependent trips, and a tile of a million-group table spent 80 microseconds on twenty of them.
+    const bool need_cnt = f.null_mode == NULL_IF_COUNT_ZERO || f.kind == FIN_COUNT || f.kind == FIN_AVG || f.kind == FIN_FIX_AVG;
+    const bool need_acc = f.null_mode == NULL_IF_ACC_ALL_ONES || f.null_mode == NULL_IF_ACC_ZERO || f.kind == FIN_ACC_I64 || f.kind == FIN_ACC_F64 ||
+                          f.kind == FIN_ACC_ORD || f.kind == FIN_AVG;
+    const unsigned long long *cnt_src = f.cnt_src == CNT_ROWS  ? T.rowcnt
+                                        : f.cnt_src == CNT_NN ? T.nn + (uint64_t)f.b * T.stride
+                                                              : T.acc + (uint64_t)f.b * T.stride;
+    const unsigned long long *acc_src = T.acc + (uint64_t)f.a * T.stride;
+    unsigned long long cnt[N], accv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      cnt[j] = (need_cnt && occupied[j]) ? cnt_src[i[j]] : 1ull;
+      accv[j] = (need_acc && occupied[j]) ? acc_src[i[j]] : 0ull;
+    }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       val[j] = 0;
       valid[j] = occupied[j];
       if (!occupied[j]) continue;
       const uint64_t at = i[j];
-      unsigned long long cnt = f.cnt_src == CNT_ROWS  ? T.rowcnt[at]
-                               : f.cnt_src == CNT_NN ? T.nn[(uint64_t)f.b * T.stride + at]
-                                                     : T.acc[(uint64_t)f.b * T.stride + at];
-      if (f.null_mode == NULL_IF_COUNT_ZERO && cnt == 0) valid[j] = false;
-      if (f.null_mode == NULL_IF_ACC_ALL_ONES && T.acc[(uint64_t)f.a * T.stride + at] == ~0ull) valid[j] = false;
-      if (f.null_mode == NULL_IF_ACC_ZERO && T.acc[(uint64_t)f.a * T.stride + at] == 0ull) valid[j] = false;
+      if (f.null_mode == NULL_IF_COUNT_ZERO && cnt[j] == 0) valid[j] = false;
+      if (f.null_mode == NULL_IF_ACC_ALL_ONES && accv[j] == ~0ull) valid[j] = false;
+      if (f.null_mode == NULL_IF_ACC_ZERO && accv[j] == 0ull) valid[j] = false;
       switch (f.kind) {
         case FIN_KEY: {
           uint64_t fm = f.bits >= 64 ? ~0ull : ((1ull << f.bits) - 1ull);
@@ -721,22 +735,22 @@ __device__ __forceinline__ void fin_emit(const FinalizeArgs &A, const uint64_t (
         }
         case FIN_ACC_I64:
         case FIN_ACC_F64:
-          val[j] = T.acc[(uint64_t)f.a * T.stride + at];
+          val[j] = accv[j];
           break;
         case FIN_ACC_ORD:
-          val[j] = valid[j] ? ord_inverse(T.acc[(uint64_t)f.a * T.stride + at], f.type) : 0;
+          val[j] = valid[j] ? ord_inverse(accv[j], f.type) : 0;
           break;
         case FIN_COUNT:
-          val[j] = cnt;
+          val[j] = cnt[j];
           break;
         case FIN_AVG:
-          val[j] = valid[j] ? d2u(u2d(T.acc[(uint64_t)f.a * T.stride + at]) / (double)cnt) : 0;
+          val[j] = valid[j] ? d2u(u2d(accv[j]) / (double)cnt[j]) : 0;
           break;
         case FIN_FIX_SUM:
           val[j] = d2u(fin_fix_sum(T, f, at));
           break;
         case FIN_FIX_AVG:
-          val[j] = valid[j] ? d2u(fin_fix_sum(T, f, at) / (double)cnt) : 0;
+          val[j] = valid[j] ? d2u(fin_fix_sum(T, f, at) / (double)cnt[j]) : 0;
           break;
         default:
           break;
@@ -780,10 +794,10 @@ __global__ __launch_bounds__(256) void qe_finalize_small_kernel(const FinalizeAr
 
 // Output position of every occupied slot: one atomic per tile of 1024 slots (counts per wave and
 // item meet in LDS), not one per slot or per wave - a million groups would otherwise queue tens of
-// thousands of atomics on the one counter.  (Measured and not kept: one reservation per workgroup for a run of
-// tiles, counted in a pass of its own - fewer, longer workgroups, 0.21 -> 0.34 ms at a million groups; a lane's four
-// slots emitted together, loads first - more registers, 0.25 ms.  The kernel waits on dependent loads from a
-// sparsely occupied table, and many short workgroups hide that best.)
+// thousands of atomics on the one counter.  A lane's four slots are emitted together, an output column at a time with
+// the four groups' loads in flight at once (fin_emit): item by item a tile was twenty dependent trips to memory, 70 to
+// 140 microseconds of them (0.225 -> 0.142 ms at a million groups).  (Measured and not kept: one reservation per
+// workgroup for a run of tiles, counted in a pass of its own - fewer, longer workgroups, 0.21 -> 0.34 ms.)
 constexpr int FIN_ITEMS = 4;
 
 __global__ __launch_bounds__(256) void qe_finalize_kernel(const FinalizeArgs A) {
@@ -811,20 +825,23 @@ __global__ __launch_bounds__(256) void qe_finalize_kernel(const FinalizeArgs A) 
       s_base = total ? atomicAdd(A.out_count, (unsigned long long)total) : 0ull;
     }
     __syncthreads();
+    uint64_t slot[FIN_ITEMS];
+    unsigned long long kk[FIN_ITEMS], pos[FIN_ITEMS], first_pos[FIN_ITEMS];
+    bool occupied[FIN_ITEMS];
 #pragma unroll
     for (int j = 0; j < FIN_ITEMS; ++j) {
-      if (occ[j] == 0) continue;
-      const uint64_t i = tile + (uint64_t)j * 256 + threadIdx.x;
-      unsigned long long k = key[j];
-      const bool occupied = k != AGG_EMPTY_KEY;
+      slot[j] = tile + (uint64_t)j * 256 + threadIdx.x;
+      kk[j] = key[j];
+      occupied[j] = kk[j] != AGG_EMPTY_KEY;
       uint32_t before = 0;
       for (int jj = 0; jj < FIN_ITEMS; ++jj)
         for (int w = 0; w < 4; ++w)
           if (jj < j || (jj == j && (uint32_t)w < wave)) before += s_count[jj][w];
-      if (i == T.cap) k = AGG_EMPTY_KEY;  // reserved slot holds the marker-valued key
-      const unsigned long long first_pos = s_base + before;
-      fin_emit<1>(A, {i}, {k}, {occupied}, {occ[j]}, {first_pos + mbcnt64(occ[j])}, {first_pos});
+      if (slot[j] == T.cap) kk[j] = AGG_EMPTY_KEY;  // reserved slot holds the marker-valued key
+      first_pos[j] = s_base + before;
+      pos[j] = first_pos[j] + mbcnt64(occ[j]);
     }
+    fin_emit<FIN_ITEMS>(A, slot, kk, occupied, occ, pos, first_pos);
     __syncthreads();  // s_count / s_base are reused by the next tile
   }
 }
