@@ -1191,8 +1191,10 @@ __device__ __forceinline__ uint32_t lds_pair_find_or_claim4(const LdsTable &L, c
       b[j] = ended ? b[j] + (e0 ? 0u : 1u) : ((b[j] + 2u) & mask);  // the empty slot itself, or the next bucket
       open &= (found || ended) ? ~(1u << j) : ~0u;
     }
-    if (__ballot(want != 0) != 0) {
-      // (rare once the table has filled: claims happen while it fills and when a key is let in later)
+    // (claims happen while the table fills and when a key is let in later.  A table that takes no more keys - the steady
+    // state of the many-groups first pass - is found out with one read for the whole step: the rows' own checks below,
+    // each behind its lane test, are four LDS round trips one after the other)
+    if (__ballot(want != 0) != 0 && *(volatile uint32_t *)L.used < L.limit) {
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) {
         bool got = false, again = false;
@@ -1222,6 +1224,85 @@ __device__ __forceinline__ uint32_t lds_pair_find_or_claim4(const LdsTable &L, c
           b[j] = again ? (b[j] & ~1u) : b[j];
         }
       }
+    }
+  }
+  return hit;
+}
+
+// The two-bucket lookup of the many-groups first pass (lds_pair_find_or_claim4<true> with two rounds) with both buckets
+// of every row read at once: at three quarters full a bucket is full without the key more often than not, the second
+// look is needed by some lane of nearly every step, and one after the other the two looks are two LDS round trips.
+__device__ __forceinline__ uint32_t lds_two_pairs_find_or_claim4(const LdsTable &L, const uint64_t (&key)[VM_R], uint32_t rows, uint32_t (&slot8)[VM_R]) {
+  const uint32_t mask = L.cap - 1;
+  uint32_t b[VM_R];
+  uint32_t hit = 0, open = rows;
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    b[j] = hash32(key[j]) & mask & ~1u;
+    slot8[j] = 0;
+  }
+  {
+    // the one key equal to the empty marker lives in the reserved slot
+    uint32_t marker = 0;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) marker |= (((rows >> j) & 1u) && key[j] == AGG_EMPTY_KEY) ? 1u << j : 0u;
+    if (__ballot(marker != 0) != 0) {
+      if (marker != 0) (void)atomicCAS(&L.keys[L.cap], AGG_EMPTY_KEY, 0ull);
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) slot8[j] = ((marker >> j) & 1u) ? L.cap * 8u : slot8[j];
+      hit |= marker;
+      open &= ~marker;
+    }
+  }
+  uint64_t k0[VM_R], k1[VM_R], k2[VM_R], k3[VM_R];
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    k0[j] = k1[j] = k2[j] = k3[j] = 0;
+    if ((open >> j) & 1u) {
+      const U64x2 first = *(const U64x2 *)__builtin_assume_aligned(&L.keys[b[j]], 16);
+      const U64x2 second = *(const U64x2 *)__builtin_assume_aligned(&L.keys[(b[j] + 2u) & mask], 16);
+      k0[j] = first.x, k1[j] = first.y, k2[j] = second.x, k3[j] = second.y;
+    }
+  }
+  uint32_t want = 0;  // rows whose probe ended at an empty slot without finding the key
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    const bool o = ((open >> j) & 1u) != 0;
+    const bool h0 = k0[j] == key[j], h1 = k1[j] == key[j], h2 = k2[j] == key[j], h3 = k3[j] == key[j];
+    const bool e0 = k0[j] == AGG_EMPTY_KEY, e1 = k1[j] == AGG_EMPTY_KEY, e2 = k2[j] == AGG_EMPTY_KEY, e3 = k3[j] == AGG_EMPTY_KEY;
+    // the first bucket decides if it holds the key or an empty slot; only a full bucket without the key sends the row on
+    const bool first_decides = h0 || h1 || e0 || e1;
+    const bool found = o && (first_decides ? (h0 || h1) : (h2 || h3));
+    const bool ended = o && !found && (first_decides || e2 || e3);
+    const uint32_t at = first_decides ? b[j] + ((h0 || (!h1 && e0)) ? 0u : 1u) : ((b[j] + 2u) & mask) + ((h2 || (!h3 && e2)) ? 0u : 1u);
+    slot8[j] = found ? at * 8u : slot8[j];
+    hit |= found ? 1u << j : 0u;
+    want |= ended ? 1u << j : 0u;
+    b[j] = at;  // (for a row that wants a slot: the empty one)
+  }
+  if (__ballot(want != 0) != 0 && *(volatile uint32_t *)L.used < L.limit) {
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) {
+      bool got = false;
+      if ((want >> j) & 1u) {
+        bool admit = *(volatile uint32_t *)L.used < L.limit;
+        if (admit && L.door) {
+          const uint32_t hf = hash32(key[j]);
+          const uint32_t d = (hf >> 12) & (DOOR_ENTRIES - 1);
+          const uint16_t tag = (uint16_t)((hf >> 16) | 1u);
+          if (*(volatile uint16_t *)&L.door[d] != tag) {
+            L.door[d] = tag;
+            admit = false;
+          }
+        }
+        if (admit) {
+          const unsigned long long old = atomicCAS(&L.keys[b[j]], AGG_EMPTY_KEY, (unsigned long long)key[j]);
+          if (old == AGG_EMPTY_KEY) atomicAdd(L.used, 1u);
+          got = old == AGG_EMPTY_KEY || old == key[j];
+        }
+      }
+      slot8[j] = got ? b[j] * 8u : slot8[j];
+      hit |= got ? 1u << j : 0u;
     }
   }
   return hit;

@@ -736,7 +736,7 @@ struct SpillRows {
 };
 
 __device__ __forceinline__ void spill_lookup(const LdsTable &L, uint32_t active, SpillRows &G, SpillState &sp, uint32_t *hist, int hist_bits) {
-  const uint32_t hit = lds_pair_find_or_claim4<true>(L, G.key, active, 2, G.slot8);
+  const uint32_t hit = lds_two_pairs_find_or_claim4(L, G.key, active, G.slot8);
   const uint32_t miss = active & ~hit;
   G.hit = hit;
   G.miss = miss;
