@@ -128,7 +128,7 @@ static Column utf8_broadcast_column(Context *ctx, const std::string &s, int64_t 
 
 // Rows idx[0..m) of several utf8 columns.  The offsets of a group of (up to sixteen) columns are computed first, their byte
 // totals come back with one synchronisation, then the bytes are copied: the host waits once per group, not once per column.
-static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<const Column *> &srcs, const int64_t *idx, int64_t m) {
+static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<const Column *> &srcs, const int32_t *idx, int64_t m) {
   // a column's control block: ticket, byte total, look-back error, one word of padding - the head of a FilterScratch,
   // of which the offsets kernel touches nothing else
   constexpr size_t GROUP = UTF8_GATHER_MAX_COLS, FIRST_WORD = 64, CONTROL_WORDS = 4, CONTROL_BYTES = CONTROL_WORDS * sizeof(unsigned long long);
@@ -286,7 +286,7 @@ static size_t lower_filter(Compiler &comp, const Schema &schema, const ExprPtr &
   if (rowid_values) {
     VmOut &o = args.outs[cnt++];
     o.pc = comp.add_rowid();
-    o.type = VT_I64;
+    o.type = VT_I32;  // (a batch with string columns has fewer than 2^31 rows: four bytes a row id, read by every gather)
     o.values = rowid_values;
     o.validity = nullptr;
   }
@@ -510,7 +510,8 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
     FilterArgs args{};
     void *rowid_values = nullptr;
     if (first && need_rowid) {
-      rowid = make_fixed_column(ctx, QE_TYPE_INT64, n, false, false);
+      if (n > 2147483647LL) fail(QE_ERR_INVALID_ARGUMENT, "a selection over string columns takes batches of at most 2^31 - 1 rows");
+      rowid = make_fixed_column(ctx, QE_TYPE_INT32, n, false, false);
       rowid_values = rowid.values->ptr;
     }
     k = lower_filter(comp, schema, pred, outs, types, vm_list, k, n, rowid_values, args, [&](int i, bool nullable, VmOut &o) {
@@ -540,7 +541,7 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
   if (!utf8_cols.empty()) {
     std::vector<const Column *> srcs;
     for (int i : utf8_cols) srcs.push_back(&in.cols[outs[i]->index]);
-    std::vector<Column> got = utf8_gather_columns(ctx, srcs, (const int64_t *)rowid.values->ptr, m);
+    std::vector<Column> got = utf8_gather_columns(ctx, srcs, (const int32_t *)rowid.values->ptr, m);
     for (size_t j = 0; j < utf8_cols.size(); ++j) out.cols[utf8_cols[j]] = std::move(got[j]);
   }
   for (int i : utf8_lits) out.cols[i] = utf8_broadcast_column(ctx, outs[i]->sval, m);

@@ -868,7 +868,7 @@ __global__ void qe_gather_rows_fixed_kernel(const FixedSource *sources, int n_so
 struct alignas(16) I32x4 { int32_t a, b, c, d; };
 constexpr int OFFSETS_THREADS = 1024, OFFSETS_TILE_MIN = 4096;  // (the status array is sized for the smallest tile)
 template <int R>  // rows a lane, consecutive: 4, 8 or 16 (measured: 4 and 8 alike, 16 much slower)
-__global__ __launch_bounds__(OFFSETS_THREADS) void qe_utf8_gather_offsets_kernel(const Utf8GatherCols C, const int64_t *idx, int64_t m, int64_t n_tiles) {
+__global__ __launch_bounds__(OFFSETS_THREADS) void qe_utf8_gather_offsets_kernel(const Utf8GatherCols C, const int32_t *idx, int64_t m, int64_t n_tiles) {
   constexpr int OFFSETS_TILE = OFFSETS_THREADS * R;
   constexpr uint32_t LANES_A_WORD = 32 / R;  // lanes whose rows share one 32-row validity word
   __shared__ int32_t s_wave[OFFSETS_THREADS / 64];
@@ -895,13 +895,13 @@ __global__ __launch_bounds__(OFFSETS_THREADS) void qe_utf8_gather_offsets_kernel
     int64_t r[R];
     if (whole) {
 #pragma unroll
-      for (int k = 0; k < R; k += 2) {
-        const U64x2 two = *(const U64x2 *)__builtin_assume_aligned(idx + i0 + k, 16);
-        r[k] = (int64_t)two.x, r[k + 1] = (int64_t)two.y;
+      for (int k = 0; k < R; k += 4) {
+        const I32x4 four = *(const I32x4 *)__builtin_assume_aligned(idx + i0 + k, 16);
+        r[k] = four.a, r[k + 1] = four.b, r[k + 2] = four.c, r[k + 3] = four.d;
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < R; ++k) r[k] = i0 + k < m ? idx[i0 + k] : -1;
+      for (int k = 0; k < R; ++k) r[k] = i0 + k < m ? (int64_t)idx[i0 + k] : -1;
     }
     int32_t len[R];
     int32_t sum = 0;
@@ -1053,7 +1053,7 @@ __device__ __forceinline__ uint32_t utf8_gather_dword(const int32_t *sd, const i
 }
 
 // Column blockIdx.y of the launch.  (src_total, the bytes of the source column: a 16-byte fetch must end inside them.)
-__global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel(const Utf8GatherCols C, const int64_t *idx, int64_t m) {
+__global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel(const Utf8GatherCols C, const int32_t *idx, int64_t m) {
   const Utf8GatherCol &col = C.col[blockIdx.y];
   const int32_t *const src_offsets = col.src_offsets;
   const uint8_t *__restrict__ const src_bytes = col.src_bytes;
@@ -1555,7 +1555,7 @@ hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream) {
 
 size_t utf8_gather_offsets_status_bytes(int64_t m) { return (size_t)((m + OFFSETS_TILE_MIN - 1) / OFFSETS_TILE_MIN) * sizeof(unsigned long long); }
 
-hipError_t launch_utf8_gather_offsets(const Utf8GatherCols &cols, const int64_t *idx, int64_t m, int cus, hipStream_t stream) {
+hipError_t launch_utf8_gather_offsets(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, int cus, hipStream_t stream) {
   if (m <= 0 || cols.n <= 0) return hipSuccess;
   if (cols.n > UTF8_GATHER_MAX_COLS || ((uintptr_t)idx & 15)) return hipErrorInvalidValue;
   for (int i = 0; i < cols.n; ++i)
@@ -1593,7 +1593,7 @@ hipError_t launch_exclusive_scan_i32(int32_t *data, int64_t n, int32_t *block_su
   return hipGetLastError();
 }
 
-hipError_t launch_utf8_gather_bytes(const Utf8GatherCols &cols, const int64_t *idx, int64_t m, hipStream_t stream) {
+hipError_t launch_utf8_gather_bytes(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, hipStream_t stream) {
   if (m <= 0 || cols.n <= 0) return hipSuccess;
   if (cols.n > UTF8_GATHER_MAX_COLS) return hipErrorInvalidValue;
   hipLaunchKernelGGL(qe_utf8_gather_bytes_kernel, dim3(grid_for(m, 256, 8192), cols.n), dim3(GATHER_WAVES * 64), 0, stream, cols, idx, m);
