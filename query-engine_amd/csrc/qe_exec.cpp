@@ -63,7 +63,9 @@ static std::vector<ExprPtr> stream_outputs(const Stream &s, int n_source_cols) {
   return o;
 }
 
-static Column make_fixed_column(Context *ctx, int type, int64_t capacity_rows, bool with_validity, bool zero_values) {
+// `cleared_validity`: a zeroed bitmap of bitmap_bytes(capacity_rows) bytes to use instead of a block of the column's own
+// (several columns' bitmaps in one block take one fill instead of a small launch each).
+static Column make_fixed_column(Context *ctx, int type, int64_t capacity_rows, bool with_validity, bool zero_values, BufferPtr cleared_validity = nullptr) {
   Column c;
   c.type = type;
   c.space = QE_MEM_DEVICE;
@@ -72,9 +74,13 @@ static Column make_fixed_column(Context *ctx, int type, int64_t capacity_rows, b
   c.values_bytes = (int64_t)vb;
   if (type == QE_TYPE_BOOLEAN || zero_values) QE_HIP(hipMemsetAsync(c.values->ptr, 0, vb, ctx->stream));
   if (with_validity) {
-    size_t bb = bitmap_bytes(capacity_rows);
-    c.validity = device_buffer(ctx, bb);
-    QE_HIP(hipMemsetAsync(c.validity->ptr, 0, bb, ctx->stream));
+    if (cleared_validity) {
+      c.validity = cleared_validity;
+    } else {
+      size_t bb = bitmap_bytes(capacity_rows);
+      c.validity = device_buffer(ctx, bb);
+      QE_HIP(hipMemsetAsync(c.validity->ptr, 0, bb, ctx->stream));
+    }
     c.null_count = -1;
   }
   return c;
@@ -146,6 +152,17 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
     }
     Utf8GatherCols launch{};
     launch.n = (int)cols;
+    // the group's validity bitmaps lie in one block, cleared by one fill (a fill per column is a small launch each,
+    // one after the other on the stream)
+    const size_t bb = bitmap_bytes(m);
+    size_t nullable = 0;
+    for (size_t j = g0; j < g1; ++j) nullable += srcs[j]->validity ? 1 : 0;
+    BufferPtr bitmaps;
+    if (nullable) {
+      bitmaps = device_buffer(ctx, nullable * bb);
+      QE_HIP(hipMemsetAsync(bitmaps->ptr, 0, nullable * bb, ctx->stream));
+    }
+    size_t next_bitmap = 0;
     for (size_t j = g0; j < g1; ++j) {
       const Column &src = *srcs[j];
       Column &c = out[j];
@@ -154,9 +171,7 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
       c.length = m;
       c.offsets = device_buffer(ctx, (size_t)(m + 1) * 4 + 16);
       if (src.validity) {
-        size_t bb = bitmap_bytes(m);
-        c.validity = device_buffer(ctx, bb);
-        QE_HIP(hipMemsetAsync(c.validity->ptr, 0, bb, ctx->stream));
+        c.validity = sub_buffer(bitmaps, next_bitmap++ * bb, bb);
         c.null_count = -1;
       }
       if (m <= 0) {
@@ -500,6 +515,15 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
   ensure_filter_scratch(ctx, n);
   ensure_counters(ctx);
   FilterScratch *scratch = (FilterScratch *)ctx->filter_scratch;
+  // the validity bitmaps of all nullable outputs in one block, cleared by one fill
+  const size_t out_bb = bitmap_bytes(n);
+  size_t nullable_outs = 0, next_bitmap = 0;
+  for (int i : vm_list) nullable_outs += expr_nullable(outs[i], schema) ? 1 : 0;
+  BufferPtr out_bitmaps;
+  if (nullable_outs > 1) {
+    out_bitmaps = device_buffer(ctx, nullable_outs * out_bb);
+    QE_HIP(hipMemsetAsync(out_bitmaps->ptr, 0, nullable_outs * out_bb, ctx->stream));
+  }
   int64_t m = 0;
   Column rowid;
   bool need_rowid = !utf8_cols.empty();
@@ -515,7 +539,8 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
       rowid_values = rowid.values->ptr;
     }
     k = lower_filter(comp, schema, pred, outs, types, vm_list, k, n, rowid_values, args, [&](int i, bool nullable, VmOut &o) {
-      Column c = make_fixed_column(ctx, types[i], n, nullable, false);
+      Column c = make_fixed_column(ctx, types[i], n, nullable, false,
+                                   nullable && out_bitmaps && next_bitmap < nullable_outs ? sub_buffer(out_bitmaps, next_bitmap++ * out_bb, out_bb) : nullptr);
       o.values = c.values->ptr;
       o.validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
       out.cols[i] = c;
