@@ -112,7 +112,12 @@ def main():
     if world > 1 and not launched:
         # nobody started the ranks for us: N fresh children, before this process touches a GPU; rank 0 prints the line
         os.environ["QE_BENCH_SPAWNED"] = "1"
-        sys.exit(launcher.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], world))
+        # a time limit and every rank's stderr in a file: a rendezvous that never completes ends here with a message,
+        # the ranks' last words and a non-zero code (QE_BENCH_TIMEOUT seconds, default 480)
+        import tempfile
+        limit = float(os.environ.get("QE_BENCH_TIMEOUT", "480"))
+        logs = os.environ.get("QE_BENCH_LOG_DIR") or tempfile.mkdtemp(prefix="qe_bench_ranks_")
+        sys.exit(launcher.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], world, timeout=limit, stderr_dir=logs))
     import torch.distributed as dist
 
     if backend == "gloo":
@@ -511,11 +516,19 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
     # the value columns per batch finds the scale, four integer accumulators replace the float one.  What it costs.
     ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_DETERMINISTIC_SUM | qe.FLAG_JIT_SYNC)
     dt, prof, out = timed(ctx, torch, headline_default, 5, 2)
-    sums_1 = out.columns()[1].values.tobytes()
-    sums_2 = headline_default().columns()[1].values.tobytes()
+
+    def sums_by_key(batch):
+        # the aggregate's rows come in table order, which changes from run to run (as the reference's HashMap order does,
+        # physical_plan/mod.rs:375-376): the witness compares each group's sum, so the rows are put in key order first
+        cols = batch.columns()
+        order = np.argsort(np.asarray(cols[0].values), kind="stable")
+        return np.asarray(cols[0].values)[order].tobytes() + np.asarray(cols[1].values)[order].tobytes()
+    sums_1 = sums_by_key(out)
+    sums_2 = sums_by_key(headline_default())
     entry("C5_headline_deterministic_sum", n, dt, prof, "qe_aggregate", BYTES_PER_ROW["c5"], len(hb),
           {"groups": out.num_rows, "same_bits_on_a_second_run": sums_1 == sums_2,
-           "host_sync": "per batch (the scale pass) and per aggregate"})
+           "host_sync": "one per aggregate (the first batch's scale pass shares it with nothing; later batches run at that scale "
+                        "and raise a flag the group-count read-back carries)"})
     ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP)
     del out
 

@@ -340,7 +340,27 @@ qe_status qe_comm_unique_id(uint8_t *id /* [QE_COMM_ID_BYTES] */);
 /* Collective over all `world` ranks (ncclCommInitRank) on the context's device
  * and stream; every exchange of this communicator is queued on that stream. */
 qe_status qe_comm_init(qe_context *ctx, int32_t rank, int32_t world, const uint8_t *id, qe_comm **out);
-/* Any of the outputs may be NULL.  rccl_version as ncclGetVersion reports it. */
+/* A communicator with no peers behind it, for running the multi-rank layouts on
+ * one GPU and for host programs that move the blocks between ranks by their own
+ * means.  Every exchange is laid out exactly as rank `rank` of `world` ranks lays
+ * it out - the owner hash and scatter of qe_exchange_by_key run over `world`
+ * owners, qe_exchange_all_gather puts this rank's table at rank * padded_rows -
+ * and the transfers are device copies on the context's stream:
+ *   qe_exchange_all_gather: the other ranks' blocks of the output are all zero
+ *     (what ranks with empty tables would have contributed);
+ *   qe_exchange_by_key: block p of the output holds what this rank sends to
+ *     rank p (over a real communicator block p holds what rank p sent here), so
+ *     block q of every rank's output, put together, is what rank q receives.
+ * Never binds RCCL.  No counterpart in the reference. */
+qe_status qe_comm_init_loopback(qe_context *ctx, int32_t rank, int32_t world, qe_comm **out);
+/* RCCL's version as ncclGetVersion reports it, binding the library if this is
+ * the first call that needs it; QE_ERR_DEVICE when no RCCL can be loaded.  Lets
+ * every rank of a job confirm that it can take part before any of them enters
+ * the collective qe_comm_init (a rank that failed there would leave the others
+ * waiting). */
+qe_status qe_comm_rccl_version(int32_t *version);
+/* Any of the outputs may be NULL.  rccl_version as ncclGetVersion reports it
+ * (0 for a loopback communicator). */
 qe_status qe_comm_info(const qe_comm *comm, int32_t *rank, int32_t *world, int32_t *rccl_version);
 void qe_comm_free(qe_comm *comm);
 /* Few groups: every rank receives every rank's partial table.  `partial`: the
@@ -365,14 +385,14 @@ qe_status qe_exchange_by_key(qe_comm *comm, const qe_batch *partial, int32_t n_k
 
 /* -------------------------------------------- selection without allocation */
 /* No counterpart in the reference.  For callers that cannot allocate device
- * memory while they run - code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc: Selection(predicate) -> Projection(exprs) over
- * one device-resident batch, the fused launch qe_plan_selection /
- * qe_plan_projection / qe_iter_next make, with every output written into
- * buffers the CALLER provides and the kernels' scratch (ticket counter, one
- * look-back status word per tile) in a fixed array inside the library instead
- * of a buffer from hipMalloc.  The call allocates no device memory, takes
- * nothing from the context's pool and compiles nothing.
+ * memory while they run - tight serving loops, harnesses that forbid hipMalloc,
+ * processes whose device memory is spoken for: Selection(predicate) ->
+ * Projection(exprs) over one device-resident batch, the fused launch
+ * qe_plan_selection / qe_plan_projection / qe_iter_next make, with every output
+ * written into buffers the CALLER provides and the kernels' scratch (ticket
+ * counter, one look-back status word per tile) in a fixed array inside the
+ * library instead of a buffer from hipMalloc.  The call allocates no device
+ * memory, takes nothing from the context's pool and compiles nothing.
  *   outs[i]: type = the expression's type (INT32 / INT64 / FLOAT64 / BOOLEAN),
  *            memory_space = QE_MEM_DEVICE, values = the buffer, length = its
  *            capacity in rows (at least the batch's rows: the number selected
@@ -384,8 +404,13 @@ qe_status qe_exchange_by_key(qe_comm *comm, const qe_batch *partial, int32_t n_k
  * one kernel launch; no Utf8 / Timestamp columns or literals (their gathers and
  * literal copies take buffers) - anything else is refused with an error, never
  * served by allocating.  Every call on one GPU shares that GPU's array (1 MiB,
- * held until the process ends): calls that overlap on one GPU race, whatever
- * their contexts or streams.  Waits for the result (the row count). */
+ * held until the process ends).  Calls from several threads of one process take
+ * turns on it (a lock per device, held until the call's result has arrived);
+ * calls from different PROCESSES on one GPU each have their own copy of the
+ * array.  The call copies the row count to the host and waits for it
+ * (hipMemcpyAsync + hipStreamSynchronize on the context's stream), so it must
+ * NOT be made on a stream that is being captured into a HIP graph: both calls
+ * are illegal there and would invalidate the capture. */
 #define QE_NOALLOC_MAX_ROWS (1ll << 29)
 qe_status qe_selection_noalloc(qe_context *ctx, const qe_batch *batch, const qe_expr *predicate, const qe_expr *const *exprs,
                                int32_t n_exprs, const qe_column *outs, int64_t *rows_out);

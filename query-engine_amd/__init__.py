@@ -111,6 +111,8 @@ ABI = {
     "qe_iter_free": (None, [C.c_void_p]),
     "qe_comm_unique_id": (C.c_int32, [C.c_char_p]),
     "qe_comm_init": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "qe_comm_init_loopback": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "qe_comm_rccl_version": (C.c_int32, [C.POINTER(C.c_int32)]),
     "qe_comm_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "qe_comm_free": (None, [C.c_void_p]),
     "qe_exchange_all_gather": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
@@ -196,9 +198,11 @@ class Context:
         _check(lib.qe_context_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
         self._h = h
         self.device = device
+        self.flags = FLAG_REFERENCE_SCALAR_ARRAY_SWAP  # the library's default
 
     def set_flags(self, flags):
         _check(lib.qe_context_set_flags(self._h, flags))
+        self.flags = flags
 
     def synchronize(self):
         _check(lib.qe_context_synchronize(self._h))
@@ -450,12 +454,23 @@ class Comm:
         _check(lib.qe_comm_unique_id(buf))
         return buf.raw
 
-    def __init__(self, ctx, rank, world, unique_id):
-        if len(unique_id) != COMM_ID_BYTES:
-            raise ValueError("unique id must be COMM_ID_BYTES long")
+    @staticmethod
+    def library_rccl_version():
+        """ncclGetVersion of the RCCL the library binds (QeError DeviceError when none can be loaded)."""
+        v = C.c_int32()
+        _check(lib.qe_comm_rccl_version(C.byref(v)))
+        return v.value
+
+    def __init__(self, ctx, rank, world, unique_id=None, loopback=False):
         h = C.c_void_p()
-        _check(lib.qe_comm_init(ctx._h, rank, world, unique_id, C.byref(h)))
-        self._h, self.ctx, self.rank, self.world = h, ctx, rank, world
+        if loopback:
+            # no peers: the exchanges are laid out as rank `rank` of `world` lays them out, moved by device copies
+            _check(lib.qe_comm_init_loopback(ctx._h, rank, world, C.byref(h)))
+        else:
+            if unique_id is None or len(unique_id) != COMM_ID_BYTES:
+                raise ValueError("unique id must be COMM_ID_BYTES long")
+            _check(lib.qe_comm_init(ctx._h, rank, world, unique_id, C.byref(h)))
+        self._h, self.ctx, self.rank, self.world, self.loopback = h, ctx, rank, world, loopback
 
     @property
     def rccl_version(self):

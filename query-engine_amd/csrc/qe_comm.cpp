@@ -159,6 +159,9 @@ struct Comm {
   std::shared_ptr<Context> ctx_ref;
   NcclComm comm = nullptr;
   int rank = 0, world = 1;
+  // No peers behind it: every exchange is laid out as rank `rank` of `world` would lay it out (owner hash over `world`
+  // owners, this rank's block at rank * padded_rows), the transfers are device copies on the context's stream.
+  bool loopback = false;
   BufferPtr counters;  // [MAX_WORLD] unsigned ints for the key-partitioned scatter
 };
 
@@ -226,9 +229,38 @@ qe_status qe_comm_init(qe_context *ctx, int32_t rank, int32_t world, const uint8
     h->c.world = world;
     NcclUniqueId u;
     std::memcpy(u.internal, id, QE_COMM_ID_BYTES);
-    QE_NCCL(rccl().CommInitRank(&h->c.comm, world, u, rank));
+    Rccl &R = rccl();  // (a library that cannot be loaded fails here, before this rank enters the collective below)
+    h->c.counters = device_buffer(c, MAX_WORLD * sizeof(unsigned int));  // and so does an allocation that cannot be had
+    QE_NCCL(R.CommInitRank(&h->c.comm, world, u, rank));
+    *out = h.release();
+  });
+}
+
+qe_status qe_comm_init_loopback(qe_context *ctx, int32_t rank, int32_t world, qe_comm **out) {
+  return qe_guarded([&] {
+    if (!ctx || !out) fail(QE_ERR_INVALID_ARGUMENT, "bad arguments");
+    *out = nullptr;
+    if (world < 1 || world > MAX_WORLD || rank < 0 || rank >= world) fail(QE_ERR_INVALID_ARGUMENT, "rank / world out of range");
+    Context *c = qe_context_ref(ctx);
+    c->bind();
+    auto h = std::make_unique<qe_comm>();
+    h->c.ctx = c;
+    h->c.ctx_ref = qe_context_share(ctx);
+    h->c.rank = rank;
+    h->c.world = world;
+    h->c.loopback = true;
     h->c.counters = device_buffer(c, MAX_WORLD * sizeof(unsigned int));
     *out = h.release();
+  });
+}
+
+qe_status qe_comm_rccl_version(int32_t *version) {
+  return qe_guarded([&] {
+    if (!version) fail(QE_ERR_INVALID_ARGUMENT, "version is null");
+    *version = 0;
+    int v = 0;
+    QE_NCCL(rccl().GetVersion(&v));
+    *version = v;
   });
 }
 
@@ -239,7 +271,7 @@ qe_status qe_comm_info(const qe_comm *comm, int32_t *rank, int32_t *world, int32
     if (world) *world = comm->c.world;
     if (rccl_version) {
       int v = 0;
-      QE_NCCL(rccl().GetVersion(&v));
+      if (!comm->c.loopback) QE_NCCL(rccl().GetVersion(&v));  // (a loopback communicator never binds RCCL: 0)
       *rccl_version = v;
     }
   });
@@ -271,14 +303,18 @@ qe_status qe_exchange_all_gather(qe_comm *comm, const qe_batch *partial, int64_t
     Batch result;
     result.ctx = ctx;
     result.rows = padded_rows * C.world;
-    Rccl &R = rccl();
     // Every rank's block lands at rank * padded_rows of the output column.  A table that already has the padded size
     // (the deferred mode's one-row-per-slot block) is sent from where it lies; a shorter one is first put into its place
-    // in the output, zero beyond its rows, and the collective runs in place.
-    const bool as_it_is = in.rows == padded_rows && padded_rows > 0;
+    // in the output, zero beyond its rows, and the collective runs in place.  Without peers (loopback) the table is
+    // always put into its place and the other ranks' blocks are what empty tables would have left there: zeros.
+    const bool as_it_is = in.rows == padded_rows && padded_rows > 0 && !C.loopback;
     for (auto &c : in.cols) {
       const size_t w = (size_t)type_width(c.type);
       Column o = exchange_column(ctx, c.type, result.rows, c.validity != nullptr);
+      if (C.loopback) {
+        if (result.rows) QE_HIP(hipMemsetAsync(o.values->ptr, 0, (size_t)result.rows * w, ctx->stream));
+        if (o.validity && result.rows) QE_HIP(hipMemsetAsync(o.validity->ptr, 0, (size_t)(result.rows / 8), ctx->stream));
+      }
       if (!as_it_is) {
         char *mine = (char *)o.values->ptr + (size_t)C.rank * padded_rows * w;
         if (in.rows) QE_HIP(hipMemcpyAsync(mine, c.values_ptr(), (size_t)in.rows * w, hipMemcpyDeviceToDevice, ctx->stream));
@@ -291,6 +327,11 @@ qe_status qe_exchange_all_gather(qe_comm *comm, const qe_batch *partial, int64_t
       }
       result.cols.push_back(o);
     }
+    if (C.loopback) {
+      *out = qe_batch_wrap(result);
+      return;
+    }
+    Rccl &R = rccl();
     QE_NCCL(R.GroupStart());
     for (size_t ci = 0; ci < result.cols.size(); ++ci) {
       Column &o = result.cols[ci];
@@ -361,6 +402,18 @@ qe_status qe_exchange_by_key(qe_comm *comm, const qe_batch *partial, int32_t n_k
       hipLaunchKernelGGL(qe_exchange_scatter_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
       QE_HIP(hipGetLastError());
       ctx->prof_end();
+    }
+    if (C.loopback) {
+      // no peers: block p of the output is what this rank would send to rank p (over a real communicator block p holds
+      // what rank p sent here), moved by device copies where the grouped send / receive pairs would move it
+      for (size_t i = 0; i < in.cols.size(); ++i) {
+        const size_t bytes = (size_t)cap * type_width(in.cols[i].type) * (size_t)C.world;
+        QE_HIP(hipMemcpyAsync(result.cols[i].values->ptr, send.cols[i].values->ptr, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        if (send.cols[i].validity)
+          QE_HIP(hipMemcpyAsync(result.cols[i].validity->ptr, send.cols[i].validity->ptr, (size_t)(result.rows / 8), hipMemcpyDeviceToDevice, ctx->stream));
+      }
+      *out = qe_batch_wrap(result);
+      return;
     }
     Rccl &R = rccl();
     QE_NCCL(R.GroupStart());

@@ -10,6 +10,7 @@
 #include <climits>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <sstream>
 #include <unordered_map>
 
@@ -1840,14 +1841,25 @@ constexpr size_t NOALLOC_SCRATCH_WORDS = sizeof(qe::FilterScratch) / 8 + (size_t
 static __device__ __align__(256) unsigned long long qe_noalloc_scratch[NOALLOC_SCRATCH_WORDS];
 constexpr int NOALLOC_MAX_DEVICES = 64;
 static unsigned long long *g_noalloc_ptr[NOALLOC_MAX_DEVICES];  // per device: where its copy of the array lives
+static std::mutex g_noalloc_setup_mutex;                         // contexts are created from any thread
+// One per device: held by qe_selection_noalloc from the reset of the array to the arrival of its result, so that calls
+// from several threads of one process (whatever their contexts and streams) take turns on the device's one array.
+static std::mutex g_noalloc_call_mutex[NOALLOC_MAX_DEVICES];
 
 // Once per device, with that device current (qe_context_create).
 static void noalloc_scratch_setup(int device) {
-  if (device < 0 || device >= NOALLOC_MAX_DEVICES || g_noalloc_ptr[device]) return;
+  if (device < 0 || device >= NOALLOC_MAX_DEVICES) return;
+  std::lock_guard<std::mutex> lock(g_noalloc_setup_mutex);
+  if (g_noalloc_ptr[device]) return;
   void *ptr = nullptr;
   hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(qe_noalloc_scratch));
   if (e != hipSuccess || !ptr) qe::fail(QE_ERR_DEVICE, std::string("hipGetSymbolAddress(qe_noalloc_scratch): ") + hipGetErrorString(e));
   g_noalloc_ptr[device] = (unsigned long long *)ptr;
+}
+static unsigned long long *noalloc_scratch_of(int device) {
+  if (device < 0 || device >= NOALLOC_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lock(g_noalloc_setup_mutex);
+  return g_noalloc_ptr[device];
 }
 
 // ==================================================================== C ABI
@@ -2527,7 +2539,7 @@ qe_status qe_selection_noalloc(qe_context *ctx, const qe_batch *batch, const qe_
       fail(QE_ERR_INVALID_ARGUMENT, "qe_selection_noalloc: " + std::to_string(n) + " rows exceed the maximum of " +
                                         std::to_string(NOALLOC_MAX_ROWS) + " (QE_NOALLOC_MAX_ROWS) its fixed scratch array serves");
     if (n_exprs > VM_MAX_OUTS) fail(QE_ERR_INVALID_ARGUMENT, "qe_selection_noalloc: at most " + std::to_string(VM_MAX_OUTS) + " output expressions");
-    unsigned long long *scratch_words = (c->device >= 0 && c->device < NOALLOC_MAX_DEVICES) ? g_noalloc_ptr[c->device] : nullptr;
+    unsigned long long *scratch_words = noalloc_scratch_of(c->device);
     if (!scratch_words) fail(QE_ERR_DEVICE, "qe_selection_noalloc: no scratch array on this device");
     for (auto &col : batch->b.cols)
       if (col.space != QE_MEM_DEVICE) fail(QE_ERR_INVALID_ARGUMENT, "batches must be device resident (qe_batch_to_device)");
@@ -2569,6 +2581,8 @@ qe_status qe_selection_noalloc(qe_context *ctx, const qe_batch *batch, const qe_
     });
     if (placed != vm_list.size() || !comp.keepalive.empty())
       fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "qe_selection_noalloc: the expressions do not fit one kernel launch");
+    // the device's one array serves one call at a time: calls from other threads of this process wait here
+    std::lock_guard<std::mutex> one_call_at_a_time(g_noalloc_call_mutex[c->device]);
     // bitmaps are written with atomic ORs into whole words: they start out zero
     const size_t words_bytes = (size_t)((n + 31) / 32) * 4;
     for (int i = 0; i < n_exprs; ++i) {

@@ -1401,8 +1401,10 @@ hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipSt
     // registers take a dominant key off the LDS atomics.
     static int lean = tuned("QE_AGGREGATE_SPILL_KERNEL", 1);
     const bool many_groups = args.spill.keys != nullptr && (args.tune & 2u) != 0;
+#ifdef QE_ABLATE  // timing experiments only (results are wrong): compiled in by a build with -DQE_ABLATE, never in the shipped library
     static int no_flush = tuned("QE_SPILL_ABLATE_FLUSH", 0);
     if (no_flush) args.tune |= 4u;
+#endif
     static int prio = tuned("QE_SPILL_PRIO", 1);
     if (prio) args.tune |= 8u;  // (bit 3: the waves of a SIMD take the high priority in turn)
     const bool spill_kernel = lean != 2 && many_groups;
@@ -1526,7 +1528,11 @@ hipError_t launch_aggregate_partitioned(const PartArgs &args, const DeviceInfo &
     attr_set = true;
   }
   int grid = args.n_parts < dev.cus ? args.n_parts : dev.cus;
+#ifdef QE_ABLATE  // timing experiments only (results are wrong): compiled in by a build with -DQE_ABLATE, never in the shipped library
   static int ablate = tuned("QE_PART_ABLATE", 0);
+#else
+  const int ablate = 0;
+#endif
   PartArgs a2 = args;
   a2.ablate = ablate;
   hipLaunchKernelGGL(qe_aggregate_partitioned_kernel, dim3(grid), dim3(PART_THREADS), lds, stream, a2);

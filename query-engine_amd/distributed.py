@@ -156,15 +156,26 @@ class KeyPartitionedExchange:
 def make_comm(qe, ctx, dist, rank, world):
     """A qe.Comm (the library's own RCCL communicator: qe_comm_init) for this rank.  The 128-byte rendezvous id is made
     by rank 0 and handed to the others through torch.distributed, whatever its backend: the exchanges themselves
-    (qe_exchange_all_gather / qe_exchange_by_key) never touch torch.  Raises qe.QeError on every rank when rank 0
-    could not make an id (no RCCL to load), so that no rank is left waiting in the rendezvous."""
-    ids, failure = [None], None
-    if rank == 0:
+    (qe_exchange_all_gather / qe_exchange_by_key) never touch torch.  Before any rank enters the collective
+    qe_comm_init, every rank confirms that it can bind RCCL and the ranks agree on that through torch.distributed: a
+    rank that could not would otherwise leave the others waiting inside the rendezvous.  Raises qe.QeError on every
+    rank when any rank cannot take part."""
+    failure = None
+    try:
+        qe.Comm.library_rccl_version()
+    except qe.QeError as e:
+        failure = e
+    ids = [None]
+    if rank == 0 and failure is None:
         try:
             ids[0] = qe.Comm.unique_id()
         except qe.QeError as e:
             failure = e
     if world > 1:
+        able = [None] * world
+        dist.all_gather_object(able, failure is None)
+        if not all(able):
+            raise failure if failure is not None else qe.QeError(41)
         dist.broadcast_object_list(ids, src=0)
     if ids[0] is None:
         raise failure if failure is not None else qe.QeError(41)

@@ -45,33 +45,56 @@ def check_world(requested, env=None):
     return world, int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", env.get("RANK", "0"))), True
 
 
-def spawn_ranks(argv, world, timeout=None, env=None, poll=0.2):
+def _tail(path, limit=4000):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, os.SEEK_END)
+            size = f.tell()
+            f.seek(max(0, size - limit))
+            return f.read().decode(errors="replace")
+    except OSError:
+        return ""
+
+
+def spawn_ranks(argv, world, timeout=None, env=None, poll=0.2, stderr_dir=None):
     """Runs `argv` once per rank (rank r gets RANK = LOCAL_RANK = r) and waits for all of them.
-    Rank 0 inherits stdout, so whatever it prints is the job's output; every rank inherits stderr.
-    Returns 0 when every rank exited with 0.  When one rank fails or the time limit passes, the others
+    Rank 0 inherits stdout, so whatever it prints is the job's output.  Every rank inherits stderr, unless
+    `stderr_dir` names a directory: then rank r writes it to <stderr_dir>/rank_<r>.stderr, and when the job
+    fails or runs out of time the end of every rank's file is copied to this process's stderr under a line that
+    says which ranks failed or were still running - a rendezvous that never completes then ends with a message
+    and a non-zero code instead of silence.
+    Returns 0 when every rank exited with 0.  When one rank fails or the time limit passes (code 124), the others
     are terminated (the exact processes started here, by pid) and the first failing code is returned."""
     if world < 1:
         raise LaunchError("world size must be at least 1")
     port = free_port()
-    procs = []
+    procs, logs = [], []
+    if stderr_dir:
+        os.makedirs(stderr_dir, exist_ok=True)
     try:
         for r in range(world):
+            log = open(os.path.join(stderr_dir, f"rank_{r}.stderr"), "wb") if stderr_dir else None
+            logs.append(log)
             procs.append(subprocess.Popen(list(argv), env=rank_environment(r, world, port, env),
-                                          stdout=None if r == 0 else subprocess.DEVNULL))
+                                          stdout=None if r == 0 else subprocess.DEVNULL, stderr=log))
         deadline = None if timeout is None else time.monotonic() + timeout
-        failed = 0
+        failed, why = 0, ""
         while True:
             codes = [p.poll() for p in procs]
-            bad = [c for c in codes if c not in (None, 0)]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
             if bad:
-                failed = bad[0]
+                failed = bad[0][1]
+                why = "rank(s) " + ", ".join(f"{r} (exit code {c})" for r, c in bad) + " failed"
                 break
             if all(c == 0 for c in codes):
                 return 0
             if deadline is not None and time.monotonic() > deadline:
                 failed = 124
+                running = [str(r) for r, c in enumerate(codes) if c is None]
+                why = f"rank(s) {', '.join(running)} still running after {timeout:.0f} s (a rendezvous or collective that never completed?)"
                 break
             time.sleep(poll)
+        print(f"launcher: {why}; stopping the other ranks", file=sys.stderr, flush=True)
         return failed
     finally:
         for p in procs:
@@ -83,6 +106,14 @@ def spawn_ranks(argv, world, timeout=None, env=None, poll=0.2):
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.wait()
+        for r, log in enumerate(logs):
+            if log is None:
+                continue
+            log.close()
+            if any(p.returncode != 0 for p in procs):
+                text = _tail(log.name)
+                if text.strip():
+                    print(f"---- rank {r} stderr (end of {log.name}) ----\n{text}", file=sys.stderr, flush=True)
 
 
 def launch_self(world, gpus_available, need_gpus=True, timeout=None):

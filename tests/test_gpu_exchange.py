@@ -133,3 +133,192 @@ def test_exchange_by_key_checks_its_bound(qe, ctx, comm):
     ctx.synchronize()  # nothing overflowed: passes
     counts = np.asarray(out.columns()[2].values)
     assert int((counts > 0).sum()) == partial.num_rows
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The layouts of more than one rank, on one GPU: a loopback communicator (qe_comm_init_loopback) lays every exchange
+# out as rank r of W ranks does - the owner hash and scatter kernel run over W owners, the all-gather puts the table at
+# r * padded_rows - and moves the blocks by device copies.  Every simulated rank runs PARTIAL over its row range; what a
+# rank would receive is put together from the simulated ranks' outputs on the host and merged by a FINAL aggregate.
+# ---------------------------------------------------------------------------------------------------------------
+def _mix64(x):
+    x = x.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint64(33)
+        x *= np.uint64(0xff51afd7ed558ccd)
+        x ^= x >> np.uint64(33)
+        x *= np.uint64(0xc4ceb9fe1a85ec53)
+        x ^= x >> np.uint64(33)
+    return x
+
+
+def _owner(keys, world):
+    """Replica of the library's owner hash for one Int64 key column: mix64(key) >> 17 modulo the ranks."""
+    return ((_mix64(np.asarray(keys).view(np.uint64)) >> np.uint64(17)) % np.uint64(world)).astype(np.int64)
+
+
+def _host_columns(batch):
+    return [(np.asarray(c.values), None if c.validity is None else np.asarray(c.validity)) for c in batch.columns()]
+
+
+def _partials(qe, ctx, k, a, b, c, world):
+    n = len(k)
+    out = []
+    for r in range(world):
+        lo, hi = r * n // world, (r + 1) * n // world
+        batch = qe.Batch.from_numpy(ctx, [k[lo:hi], a[lo:hi], b[lo:hi], c[lo:hi]])
+        out.append(list(_local_plan(qe, qe.ScanExec(ctx, [batch]), qe.AGG_MODE_PARTIAL).execute())[0])
+    return out
+
+
+def _final_of(qe, ctx, cols, hint):
+    """FINAL aggregate over host columns [(values, validity)] of exchanged partial tables (unfilled rows: COUNT(*) = 0)."""
+    batch = qe.Batch.from_numpy(ctx, [v if m is None else (v, m) for v, m in cols])
+    first, _ = qe.partial_layout(1, _aggs(qe))
+    real = qe.SelectionExec([qe.ScanExec(ctx, [batch])], qe.GtExpression(qe.ColumnExpression(first[1]), qe.LiteralInt64Expression(0)))
+    return list(qe.final_plan(real, 1, _aggs(qe), group_capacity_hint=hint).execute())[0]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_loopback_all_gather_layout_of_every_rank(qe, ctx, world):
+    k, a, b, c = _table(240_000, 300, seed=13)
+    partials = _partials(qe, ctx, k, a, b, c, world)
+    padded = (max(p.num_rows for p in partials) + 31) // 32 * 32 + 32
+    union = None
+    for r, partial in enumerate(partials):
+        comm = qe.Comm(ctx, r, world, loopback=True)
+        assert comm.rccl_version == 0
+        for _ in range(2):  # pool buffers are reused between steps
+            got = comm.all_gather(partial, padded)
+        comm.close()
+        assert got.num_rows == world * padded and got.num_columns == partial.num_columns
+        mine, cols = _host_columns(partial), _host_columns(got)
+        rows = partial.num_rows
+        assert any(m is not None for _, m in mine)  # MIN / MAX of a Float64 column can be null: their bits travel too
+        for (v, m), (pv, pm) in zip(cols, mine):
+            # this rank's table at rank * padded_rows, bit for bit; zero everywhere else
+            block = v[r * padded:r * padded + rows]
+            assert np.array_equal(block.view(np.uint64) if block.dtype == np.float64 else block, pv.view(np.uint64) if pv.dtype == np.float64 else pv)
+            outside = np.ones(len(v), bool)
+            outside[r * padded:r * padded + rows] = False
+            assert not v[outside].view(np.uint64 if v.dtype.itemsize == 8 else np.uint32).any()
+            assert (m is None) == (pm is None)
+            if m is not None:
+                assert np.array_equal(m[r * padded:r * padded + rows], pm) and not m[outside].any()
+        if union is None:
+            union = [(v.copy(), None if m is None else m.copy()) for v, m in cols]
+        else:
+            for (uv, um), (v, m) in zip(union, cols):
+                w = np.uint64 if uv.dtype.itemsize == 8 else np.uint32
+                uv.view(w)[:] |= v.view(w)  # blocks of different ranks never overlap: OR puts them side by side
+                if um is not None:
+                    um |= m
+    # what a real all-gather leaves on every rank -> FINAL = the aggregate of the whole table
+    _check(qe, _final_of(qe, ctx, union, 4096), k, a, b, c)
+
+
+@pytest.mark.parametrize("world,n,n_keys", [(2, 300_000, 3_000), (8, 1_200_000, 90_000)])
+def test_loopback_exchange_by_key_layout_of_every_rank(qe, ctx, world, n, n_keys):
+    k, a, b, c = _table(n, n_keys, seed=17)
+    partials = _partials(qe, ctx, k, a, b, c, world)
+    bound = max(p.num_rows for p in partials)
+    first, _ = qe.partial_layout(1, _aggs(qe))
+    count_col = first[1]
+    outs = []
+    for r, partial in enumerate(partials):
+        comm = qe.Comm(ctx, r, world, loopback=True)
+        for _ in range(2):
+            got = comm.exchange_by_key(partial, 1, bound)
+        ctx.synchronize()  # would report a peer block that overflowed
+        comm.close()
+        cols = _host_columns(got)
+        cap = got.num_rows // world
+        assert cap * world == got.num_rows and cap % 32 == 0
+        keys, counts = cols[0][0], cols[count_col][0]
+        real = counts > 0
+        # every row in the block of the rank that owns its key; the blocks' rows sum to the table
+        assert int(real.sum()) == partial.num_rows
+        block_of_row = np.arange(got.num_rows) // cap
+        assert np.array_equal(_owner(keys[real], world), block_of_row[real])
+        # rows are filled from the front of their block
+        for p in range(world):
+            filled = int(real[p * cap:(p + 1) * cap].sum())
+            assert real[p * cap:p * cap + filled].all()
+        # every column's values and validity bits landed with their rows; unfilled rows are zero
+        mine = _host_columns(partial)
+        order_in = np.argsort(mine[0][0], kind="stable")
+        order_out = np.argsort(keys[real], kind="stable")
+        for (v, m), (pv, pm) in zip(cols, mine):
+            w = np.uint64 if v.dtype.itemsize == 8 else np.uint32
+            assert np.array_equal(v[real][order_out].view(w), pv[order_in].view(w))
+            assert not v[~real].view(w).any()
+            assert (m is None) == (pm is None)
+            if m is not None:
+                assert np.array_equal(m[real][order_out], pm[order_in]) and not m[~real].any()
+        outs.append((cols, cap))
+    # rank q receives block q of every rank's send buffer; its FINAL aggregate gives its share of the groups
+    shares = []
+    for q in range(world):
+        received = []
+        for ci in range(len(outs[0][0])):
+            vals = np.concatenate([cols[ci][0][q * cap:(q + 1) * cap] for cols, cap in outs])
+            masks = None if outs[0][0][ci][1] is None else np.concatenate([cols[ci][1][q * cap:(q + 1) * cap] for cols, cap in outs])
+            received.append((vals, masks))
+        if not (received[count_col][0] > 0).any():
+            continue
+        share = _final_of(qe, ctx, received, max(64, 2 * n_keys // world)).columns()
+        assert (_owner(np.asarray(share[0].values), world) == q).all()
+        shares.append(share)
+    # the result is the concatenation over the ranks: no key on two ranks, every group there
+    all_keys = np.concatenate([np.asarray(s[0].values) for s in shares])
+    assert len(np.unique(all_keys)) == len(all_keys)
+
+    class _Cat:
+        def __init__(self, cols):
+            self._cols = cols
+
+        def columns(self):
+            return self._cols
+    cat = []
+    for ci in range(len(shares[0])):
+        col = qe.Column(shares[0][ci].type, np.concatenate([np.asarray(s[ci].values) for s in shares]))
+        cat.append(col)
+    _check(qe, _Cat(cat), k, a, b, c)
+
+
+def test_loopback_exchange_by_key_reports_a_block_that_overflows(qe, ctx):
+    """Keys that all belong to one rank: its block (an even share plus a quarter) cannot hold them, which the next
+    synchronise reports (AggregateCapacity) - nothing in the exchange itself waits for the device."""
+    r = np.random.default_rng(23)
+    cand = np.unique(r.integers(0, 1 << 40, 200_000).astype(np.int64))
+    keys = cand[_owner(cand, 2) == 0][:40_000]
+    assert len(keys) == 40_000
+    n = len(keys) * 3
+    k = np.tile(keys, 3)
+    a, b, c = r.uniform(-1, 1, n), r.uniform(-1, 1, n), r.uniform(0.6, 1, n)
+    batch = qe.Batch.from_numpy(ctx, [k, a, b, c])
+    partial = list(_local_plan(qe, qe.ScanExec(ctx, [batch]), qe.AGG_MODE_PARTIAL).execute())[0]
+    assert partial.num_rows == 40_000
+    comm = qe.Comm(ctx, 1, 2, loopback=True)
+    try:
+        comm.exchange_by_key(partial, 1, partial.num_rows)  # returns at once
+        with pytest.raises(qe.QeError) as e:
+            ctx.synchronize()
+        assert e.value.name == "AggregateCapacity"
+        ctx.synchronize()  # reported once
+        # with room for the skew it goes through, and every row is in rank 0's block
+        out = comm.exchange_by_key(partial, 1, 4 * partial.num_rows)
+        ctx.synchronize()
+        counts = np.asarray(out.columns()[2].values)
+        cap = out.num_rows // 2
+        assert int((counts[:cap] > 0).sum()) == partial.num_rows and not (counts[cap:] > 0).any()
+    finally:
+        comm.close()
+
+
+def test_loopback_communicator_checks_its_arguments(qe, ctx):
+    for rank, world in ((2, 2), (-1, 2), (0, 0), (0, 65)):
+        with pytest.raises(qe.QeError) as e:
+            qe.Comm(ctx, rank, world, loopback=True)
+        assert e.value.name == "InvalidArgument"
+    assert qe.Comm.library_rccl_version() > 0

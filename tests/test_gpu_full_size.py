@@ -122,6 +122,47 @@ def test_c5_whole_equals_merge_of_parts_1b(qe, torch_ctx):
         assert abs(whole[3][i] - ref / whole[2][i]) <= REL * mag / whole[2][i]
 
 
+def test_deterministic_sum_same_bits_at_headline_size(qe, torch_ctx):
+    """QE_FLAG_DETERMINISTIC_SUM on the headline's shape: 800 M rows in three batches of 2^28, generated on the device.
+    Two runs give the same bits group by group (rows put in key order: the table's order changes from run to run, as the
+    reference's HashMap order does, physical_plan/mod.rs:375-376), and the sums lie within 1e-12 of the magnitudes summed
+    of a torch tree reduction.  The reference folds in one fixed order (physical_plan/mod.rs:340-372); what is promised
+    here is identity from run to run."""
+    torch, ctx = torch_ctx
+    n = 3 << 28
+    k, a, b, c = table(torch, ctx, n)
+    C = qe.ColumnExpression
+    step = 1 << 28
+    batches = [qe.Batch.from_torch(ctx, [t[s:s + step] for t in (k, a, b, c)]) for s in range(0, n, step)]
+    assert len(batches) == 3
+
+    def run():
+        sel = qe.SelectionExec([qe.ScanExec(ctx, batches)], qe.GtExpression(C(3), qe.LiteralFloatExpression(0.5)))
+        proj = qe.ProjectionExec([sel], [C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
+        plan = qe.AggregateExec([proj], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None), qe.AvgExpression(C(1))], group_capacity_hint=64)
+        return by_key(list(plan.execute())[0].columns())
+    saved = ctx.flags
+    ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_DETERMINISTIC_SUM | qe.FLAG_JIT_SYNC)
+    try:
+        one, two, three = run(), run(), run()
+    finally:
+        ctx.set_flags(saved)
+    for other in (two, three):
+        assert np.array_equal(one[0], other[0]) and np.array_equal(one[2], other[2])
+        assert np.array_equal(one[1].view(np.uint64), other[1].view(np.uint64)), "SUM differs in its bits between two runs"
+        assert np.array_equal(one[3].view(np.uint64), other[3].view(np.uint64)), "AVG differs in its bits between two runs"
+    keep = c > 0.5
+    assert one[2].sum() == int(keep.sum())
+    v = a + b * c
+    zero = torch.zeros((), dtype=torch.float64, device="cuda")
+    for i, key in enumerate(one[0]):
+        mine = keep & (k == int(key))
+        ref = float(torch.where(mine, v, zero).sum())  # torch.sum reduces as a tree
+        mag = float(torch.where(mine, v.abs(), zero).sum())
+        assert abs(one[1][i] - ref) <= REL * mag
+        assert abs(one[3][i] - ref / one[2][i]) <= REL * mag / one[2][i]
+
+
 def test_one_batch_past_2_to_31_rows(qe, torch_ctx):
     """2.4 G rows in a single batch: row positions and counts are 64-bit all the way."""
     torch, ctx = torch_ctx
