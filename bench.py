@@ -527,8 +527,8 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
     sums_2 = sums_by_key(headline_default())
     entry("C5_headline_deterministic_sum", n, dt, prof, "qe_aggregate", BYTES_PER_ROW["c5"], len(hb),
           {"groups": out.num_rows, "same_bits_on_a_second_run": sums_1 == sums_2,
-           "host_sync": "one per aggregate (the first batch's scale pass shares it with nothing; later batches run at that scale "
-                        "and raise a flag the group-count read-back carries)"})
+           "host_sync": "one for the scale (a pass over the first 2^22 rows of the first batch) and one per aggregate (the group "
+                        "count, with the word the kernels set when a later value does not fit that scale)"})
     ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP)
     del out
 

@@ -258,11 +258,12 @@ ExprPtr make_key_hash(ExprPtr before, ExprPtr column) {
   return n;
 }
 
-ExprPtr make_fix(int part, ExprPtr value, int scale) {
+ExprPtr make_fix(int part, ExprPtr value, int scale, uint64_t overflow_word) {
   auto n = std::make_shared<Expr>();
   n->kind = EK_BINARY;
   n->fix = part;
   n->ival = scale;
+  n->fix_overflow_word = overflow_word;
   n->l = std::move(value);
   return n;
 }
@@ -597,6 +598,7 @@ ExprCost expr_cost(const ExprPtr &e, const Schema &schema) {
     c = expr_cost(e->l, schema);
     c.insns += 1;
     if (e->fix >= FIX_LIMB0 && e->fix <= FIX_LIMB2) c.lits += 1;
+    if (e->fix == FIX_SPECIAL) c.lits += 2;  // the scale and the overflow word's address
     return c;
   }
   if (expr_type(e->l, schema) == QE_TYPE_UTF8) {  // one comparison instruction; a literal operand is (address, length)
@@ -772,7 +774,11 @@ void Compiler::emit(const ExprPtr &e, int depth) {
     emit(e->l, depth);
     switch (e->fix) {
       case FIX_EXPONENT: push_insn(OP_FIX_EXP, depth + 1, 0); break;
-      case FIX_SPECIAL: push_insn(OP_FIX_SPECIAL, depth + 1, 0); break;
+      case FIX_SPECIAL: {
+        const uint32_t scale = (uint32_t)lit_slot((uint64_t)e->ival), word = (uint32_t)lit_slot(e->fix_overflow_word);
+        push_insn(OP_FIX_SPECIAL, depth + 1, scale | (word << 8));
+        break;
+      }
       default: push_insn(OP_FIX_LIMB0 + (uint32_t)(e->fix - FIX_LIMB0), depth + 1, (uint32_t)lit_slot((uint64_t)e->ival)); break;
     }
     return;

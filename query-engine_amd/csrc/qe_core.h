@@ -148,6 +148,9 @@ struct Expr {
   // (FIX_EXPONENT: its exponent field; FIX_LIMB0 + k: limb k of its fixed-point image at scale `ival`; FIX_SPECIAL:
   // infinity / NaN marks), of type Int64
   int fix = 0;
+  // FIX_SPECIAL: device address of the word the kernels set when a finite value does not fit the limbs at the scale
+  // (0 = nobody is listening).  An address, not part of the expression's identity.
+  uint64_t fix_overflow_word = 0;
   ExprPtr l, r;
 };
 
@@ -167,7 +170,7 @@ ExprPtr make_hash_utf8(ExprPtr column);
 ExprPtr make_key_hash(ExprPtr before, ExprPtr column);
 ExprPtr make_rowid(int64_t base);
 enum FixPart { FIX_NONE = 0, FIX_EXPONENT = 1, FIX_LIMB0 = 2, FIX_LIMB1 = 3, FIX_LIMB2 = 4, FIX_SPECIAL = 5 };
-ExprPtr make_fix(int part, ExprPtr value, int scale);
+ExprPtr make_fix(int part, ExprPtr value, int scale, uint64_t overflow_word = 0);
 std::string expr_to_string(const ExprPtr &e);
 std::string expr_identity(const ExprPtr &e);  // equal exactly for equal trees (expr_to_string is the reference's ambiguous Display)
 bool expr_is_scalar(const ExprPtr &e);

@@ -436,8 +436,14 @@ __device__ __forceinline__ uint64_t fix_exponent(uint64_t bits) {
   const uint32_t e = (uint32_t)(bits >> 52) & 0x7ffu;
   return e == 0x7ffu ? 0 : e;
 }
-__device__ __forceinline__ uint64_t fix_special(uint64_t bits) {
-  if (((bits >> 52) & 0x7ffu) != 0x7ffu) return 0;
+// The infinity / NaN marks of x.  A finite x of a row that takes part (`live`) with |x| >= 2^S does not fit the limbs at
+// scale S: `overflow` (when given) is set, and the host, which chose S without having seen every value, starts over.
+__device__ __forceinline__ uint64_t fix_special(uint64_t bits, int S, unsigned long long *overflow, bool live) {
+  const uint32_t e = (uint32_t)(bits >> 52) & 0x7ffu;
+  if (e != 0x7ffu) {
+    if (overflow != nullptr && live && (int)e - 1023 >= S) __hip_atomic_store(overflow, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0;
+  }
   if (bits & 0xfffffffffffffull) return 1ull | (1ull << 32);
   return (bits >> 63) ? 1ull << 32 : 1ull;
 }
@@ -643,8 +649,10 @@ __device__ __forceinline__ void vm_slow(uint32_t op, uint32_t d, uint32_t arg, c
       break;
     }
     case OP_FIX_SPECIAL: {
+      const int S = (int)(int64_t)P.lits[arg & 0xffu];
+      unsigned long long *overflow = (unsigned long long *)(uintptr_t)P.lits[(arg >> 8) & 0xffu];
 #pragma unroll
-      for (int j = 0; j < VM_R; ++j) a.v[j] = fix_special(a.v[j]);
+      for (int j = 0; j < VM_R; ++j) a.v[j] = fix_special(a.v[j], S, overflow, ((c.active & a.valid) >> j) & 1u);
       break;
     }
     case OP_DIV_F64: {

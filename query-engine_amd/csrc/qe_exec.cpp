@@ -671,11 +671,12 @@ static bool key_tuple_hashed(const std::vector<int> &types) {
 
 // An order-independent Float64 sum of `x` at scale `S`: three integer sums of the limbs of x's fixed-point image and
 // one of its infinity / NaN marks, in consecutive accumulators; the first one's index.
-static int add_fix_sum(AggSpec &spec, const ExprPtr &x, int S, bool track_nn) {
+// `overflow_word`: device address of the word a kernel sets when a value does not fit scale S (0: S is known to fit).
+static int add_fix_sum(AggSpec &spec, const ExprPtr &x, int S, bool track_nn, uint64_t overflow_word) {
   const int a = add_acc(spec, ACC_SUM_I64, QE_TYPE_INT64, track_nn, make_fix(FIX_LIMB0, x, S));
   const int b = add_acc(spec, ACC_SUM_I64, QE_TYPE_INT64, false, make_fix(FIX_LIMB1, x, S));
   const int c = add_acc(spec, ACC_SUM_I64, QE_TYPE_INT64, false, make_fix(FIX_LIMB2, x, S));
-  const int d = add_acc(spec, ACC_SUM_I64, QE_TYPE_INT64, false, make_fix(FIX_SPECIAL, x, 0));
+  const int d = add_acc(spec, ACC_SUM_I64, QE_TYPE_INT64, false, make_fix(FIX_SPECIAL, x, S, overflow_word));
   if (b != a + 1 || c != a + 2 || d != a + 3) fail(QE_ERR_INTERNAL, "the accumulators of an order-independent sum are not consecutive");
   return a;
 }
@@ -683,7 +684,8 @@ static int add_fix_sum(AggSpec &spec, const ExprPtr &x, int S, bool track_nn) {
 // `fix_scales`: per aggregate the scale of its order-independent sum (QE_FLAG_DETERMINISTIC_SUM), or null.
 static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::vector<ExprPtr> &groups,
                               const std::vector<AggExpr> &aggs, const std::vector<ExprPtr> &aggs_second, int mode,
-                              int64_t row_base = 0, bool emit_row_number = false, const std::vector<int> *fix_scales = nullptr) {
+                              int64_t row_base = 0, bool emit_row_number = false, const std::vector<int> *fix_scales = nullptr,
+                              uint64_t fix_overflow_word = 0) {
   AggSpec spec;
   int shift = 0;
   if ((int)groups.size() > MAX_HASHED_KEYS) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many group expressions.");
@@ -785,7 +787,7 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
         need_numeric();
         bool f64 = t == QE_TYPE_FLOAT64;
         if (f64 && fix_scales) {
-          const int a = add_fix_sum(spec, e, (*fix_scales)[i], nullable);
+          const int a = add_fix_sum(spec, e, (*fix_scales)[i], nullable, fix_overflow_word);
           FinOut f = fin(FIN_FIX_SUM, t, a, a, CNT_NN, nullable ? NULL_IF_COUNT_ZERO : NULL_NEVER);
           f.scale = (int16_t)(*fix_scales)[i];
           spec.outs.push_back(f);
@@ -813,7 +815,7 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
           ExprPtr cnt_e = aggs_second[i] ? expr_normalize(aggs_second[i], flags) : nullptr;
           if (!e || t != QE_TYPE_FLOAT64 || !cnt_e || expr_type(cnt_e, schema) != QE_TYPE_INT64)
             fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "AVG partial columns must be (Float64 sum, Int64 count).");
-          int a = fix_scales ? add_fix_sum(spec, e, (*fix_scales)[i], false) : add_acc(spec, ACC_SUM_F64, QE_TYPE_FLOAT64, false, e);
+          int a = fix_scales ? add_fix_sum(spec, e, (*fix_scales)[i], false, fix_overflow_word) : add_acc(spec, ACC_SUM_F64, QE_TYPE_FLOAT64, false, e);
           int b = add_acc(spec, ACC_SUM_I64, QE_TYPE_INT64, false, cnt_e);
           FinOut f = fin(fix_scales ? FIN_FIX_AVG : FIN_AVG, QE_TYPE_FLOAT64, a, b, CNT_ACC, NULL_IF_COUNT_ZERO);
           if (fix_scales) f.scale = (int16_t)(*fix_scales)[i];
@@ -823,7 +825,7 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
         need_numeric();
         // (a Float64 input needs no cast: AVG(x) then shares SUM(x)'s accumulator)
         const ExprPtr as_f64 = t == QE_TYPE_FLOAT64 ? e : make_to_f64(e);
-        int a = fix_scales ? add_fix_sum(spec, as_f64, (*fix_scales)[i], false) : add_acc(spec, ACC_SUM_F64, QE_TYPE_FLOAT64, false, as_f64);
+        int a = fix_scales ? add_fix_sum(spec, as_f64, (*fix_scales)[i], false, fix_overflow_word) : add_acc(spec, ACC_SUM_F64, QE_TYPE_FLOAT64, false, as_f64);
         int b = -1;
         uint8_t src = CNT_ROWS;
         if (nullable) {
@@ -1095,6 +1097,24 @@ static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &
 // batches whose redundant validity buffers were ignored, does not have: the caller starts over with
 // `strict` set, which takes every validity buffer at face value.
 struct NeedsStrictNullability {};
+// Thrown by AggState::finish when an order-independent sum ran at a scale chosen without having seen every value and
+// a value turned out not to fit it: the caller starts over with `fix_exact` set, which finds every batch's scale by a
+// pass of its own before the batch is folded in.
+struct NeedsExactScales {};
+// Rows of the first batch an order-independent sum looks at to choose its scale when it does not look at all of them.
+constexpr int64_t FIX_PROBE_ROWS = (int64_t)1 << 22;
+constexpr int FIX_PROBE_MARGIN = 8;  // bits of headroom above what those rows need
+
+static Batch batch_prefix(const Batch &b, int64_t rows) {
+  Batch p = b;
+  p.rows = rows;
+  for (auto &c : p.cols) {
+    c.length = rows;
+    if (c.null_count > 0) c.null_count = -1;
+    if (type_width(c.type)) c.values_bytes = rows * type_width(c.type);
+  }
+  return p;
+}
 
 struct AggState {
   Context *ctx = nullptr;
@@ -1125,6 +1145,15 @@ struct AggState {
   int64_t fix_rows = 0;
   bool no_defer = false;
   bool fix_wanted() const { return (ctx->flags & QE_FLAG_DETERMINISTIC_SUM) != 0; }
+  // How the scales are found.  Exact: a pass over every batch before it is folded in (one more read of the value
+  // columns and a wait per batch).  Otherwise the scale comes from the first rows of the first batch that has any, with
+  // some headroom, every later batch runs at it, and a value that does not fit sets `fix_overflow` on the device - read
+  // with the group count at the end, upon which the aggregation starts over with exact scales.  Either way the scale
+  // is a function of the data alone, so the sums' bits are too.  An aggregate that must not wait for the device
+  // (deferred group count) cannot start over: exact scales.
+  bool fix_exact = false;
+  BufferPtr fix_overflow;
+  bool fix_optimistic() const { return fix_wanted() && !fix_exact && !(ctx->flags & QE_FLAG_DEFERRED_GROUP_COUNT); }
 
   int acc_weight(const AggExpr &a) const {  // accumulators an aggregate may take
     const bool fix = fix_wanted();
@@ -1154,6 +1183,7 @@ struct AggState {
         auto p = std::make_unique<AggState>();
         p->ctx = ctx;
         p->strict = strict;
+        p->fix_exact = fix_exact;
         p->groups = groups;
         p->mode = mode;
         p->cap_hint = effective_hint();
@@ -1174,6 +1204,7 @@ struct AggState {
     row_base = 0;
     fix_scale.clear();
     fix_rows = 0;
+    fix_overflow.reset();
   }
 
   // The scale each order-independent sum needs for this batch: the smallest multiple of 8 with |value| < 2^scale for
@@ -1263,7 +1294,27 @@ struct AggState {
       fix_rows += in.rows;
       if (fix_rows > ((int64_t)1 << 31)) fail(QE_ERR_INVALID_ARGUMENT, "QE_FLAG_DETERMINISTIC_SUM: more than 2^31 rows in one aggregate");
       if (fix_scale.empty()) fix_scale.assign(aggs.size(), INT_MIN);
-      const std::vector<int> need = batch_scales(in_raw, outputs, pred, is_fix);
+      std::vector<int> need(aggs.size(), INT_MIN);
+      if (!fix_optimistic()) {
+        need = batch_scales(in_raw, outputs, pred, is_fix);
+      } else {
+        if (!fix_overflow) {
+          fix_overflow = device_buffer(ctx, 256);
+          QE_HIP(hipMemsetAsync(fix_overflow->ptr, 0, 8, ctx->stream));
+        }
+        auto unknown = [&](const std::vector<int> &found) {
+          for (size_t i = 0; i < aggs.size(); ++i)
+            if (is_fix[i] && fix_scale[i] == INT_MIN && found[i] == INT_MIN) return true;
+          return false;
+        };
+        if (unknown(need)) {  // (some sum has no scale yet)
+          std::vector<int> found = in_raw.rows > FIX_PROBE_ROWS ? batch_scales(batch_prefix(in_raw, FIX_PROBE_ROWS), outputs, pred, is_fix)
+                                                                : batch_scales(in_raw, outputs, pred, is_fix);
+          if (in_raw.rows > FIX_PROBE_ROWS && unknown(found)) found = batch_scales(in_raw, outputs, pred, is_fix);  // the predicate let none of the first rows through
+          for (size_t i = 0; i < aggs.size(); ++i)
+            if (is_fix[i] && fix_scale[i] == INT_MIN && found[i] != INT_MIN) need[i] = found[i] + FIX_PROBE_MARGIN;
+        }
+      }
       std::vector<int> moved;
       for (size_t i = 0; i < aggs.size(); ++i) {
         if (!is_fix[i] || need[i] <= fix_scale[i]) continue;
@@ -1308,7 +1359,8 @@ struct AggState {
       fitter.fit_together(all, 12 + 5 * (int)g2.size() + (int)a2.size(), 4);
       if (fitter.temporaries) schema = fitter.schema;
     }
-    AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode, row_base, emit_row_number, any_fix ? &scales_now : nullptr);
+    AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode, row_base, emit_row_number, any_fix ? &scales_now : nullptr,
+                                   any_fix && fix_overflow ? (uint64_t)(uintptr_t)fix_overflow->ptr : 0);
     key_sources.resize(bspec.key_gathers.size());
     for (size_t i = 0; i < bspec.key_gathers.size(); ++i) key_sources[i].push_back(Utf8KeySource{in.cols[bspec.key_gathers[i].col], row_base});
     row_base += in.rows;
@@ -1496,9 +1548,18 @@ struct AggState {
     const bool eager = table.cap + 1 <= (1u << 16);
     if (deferred_wanted()) return finish_deferred(result);
     unsigned long long n_groups = 0, overflow = 0;
+    // (the word an order-independent sum's kernels set when a value did not fit the scale travels with the control words)
+    auto queue_scale_check = [&] {
+      if (fix_overflow) QE_HIP(hipMemcpyAsync(ctx->host_counters + 20, fix_overflow->ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    };
+    auto scale_check = [&] {
+      if (fix_overflow && ctx->host_counters[20]) throw NeedsExactScales{};
+    };
     if (!eager) {
       QE_HIP(hipMemcpyAsync(ctx->host_counters + 16, table.ctrl, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+      queue_scale_check();
       ctx->sync();
+      scale_check();
       n_groups = ctx->host_counters[16];
       overflow = ctx->host_counters[17];
       if (overflow) return false;
@@ -1526,7 +1587,9 @@ struct AggState {
     ctx->prof_end();
     if (eager) {
       QE_HIP(hipMemcpyAsync(ctx->host_counters + 16, table.ctrl, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+      queue_scale_check();
       ctx->sync();
+      scale_check();
       n_groups = ctx->host_counters[16];
       overflow = ctx->host_counters[17];
       if (overflow) return false;
@@ -1573,9 +1636,14 @@ struct AggIter : Iter {
         st.strict = true;  // a later batch has nulls where the earlier ones had none: once more, tracking them
         continue;
       }
-      if (st.finish(result)) {
-        done = true;
-        return;
+      try {
+        if (st.finish(result)) {
+          done = true;
+          return;
+        }
+      } catch (const NeedsExactScales &) {
+        st.fix_exact = true;  // a value did not fit the scale the first rows suggested: once more, every batch's scale found first
+        continue;
       }
       // grow (a full table says little about how many groups there are: a big step, up to the largest table) and run the aggregation again
       if (st.cap >= (1ull << 30)) break;
@@ -2452,15 +2520,23 @@ qe_status qe_agg_finalize(qe_agg_state *state, qe_batch **out) {
     *out = nullptr;
     if (!state->started) fail(QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE, "The hashmap for aggregation is empty.");
     Batch result;
-    for (int attempt = 0; attempt < 6; ++attempt) {
-      if (state->st.finish(result)) {
-        result.ctx = state->st.ctx;
-        *out = new qe_batch{result};
-        return;
+    for (int attempt = 0; attempt < 7; ++attempt) {
+      bool grow = true;
+      try {
+        if (state->st.finish(result)) {
+          result.ctx = state->st.ctx;
+          *out = new qe_batch{result};
+          return;
+        }
+      } catch (const NeedsExactScales &) {
+        state->st.fix_exact = true;  // an order-independent sum met a value beyond its scale: everything once more, scales found first
+        grow = false;
       }
       // the table overflowed: a larger one, and everything seen so far folded in again
-      if (state->st.cap >= (1ull << 30)) break;
-      state->hint = std::min<int64_t>((int64_t)state->st.cap * 16, (int64_t)1 << 29);
+      if (grow) {
+        if (state->st.cap >= (1ull << 30)) break;
+        state->hint = std::min<int64_t>((int64_t)state->st.cap * 16, (int64_t)1 << 29);
+      }
       state->st.start(state->hint);
       for (auto &b : state->history) state->st.update(b, {}, nullptr);
     }

@@ -155,8 +155,10 @@ __device__ __forceinline__ void eval_static(const VmProgram &P, const RowCtx &c,
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) S[d - 1].v[j] = fix_limb(S[d - 1].v[j], scale, (int)(op - OP_FIX_LIMB0));
     } else if constexpr (op == OP_FIX_SPECIAL) {
+      const int scale = (int)(int64_t)P.lits[arg & 0xffu];
+      unsigned long long *overflow = (unsigned long long *)(uintptr_t)P.lits[(arg >> 8) & 0xffu];
 #pragma unroll
-      for (int j = 0; j < VM_R; ++j) S[d - 1].v[j] = fix_special(S[d - 1].v[j]);
+      for (int j = 0; j < VM_R; ++j) S[d - 1].v[j] = fix_special(S[d - 1].v[j], scale, overflow, ((c.active & S[d - 1].valid) >> j) & 1u);
     } else if constexpr (op == OP_DIV_F64) {
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) S[d - 2].v[j] = d2u(u2d(S[d - 2].v[j]) / u2d(S[d - 1].v[j]));

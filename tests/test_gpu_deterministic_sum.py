@@ -189,3 +189,46 @@ def test_partial_then_final(qe, det_ctx):
     for key, s, avg in zip(one[0].tolist(), one[1].tolist(), one[3].tolist()):
         e, mag, m = exact[key]
         assert abs(s - e) <= REL * mag and abs(avg - e / m) <= REL * mag / m
+
+
+def test_a_value_beyond_the_scale_the_first_rows_suggest(qe, det_ctx):
+    """The scale comes from the first 2^22 rows of the first batch (with 8 bits to spare); here the rows after them are
+    2^70 times larger.  The kernels notice, the aggregation starts over with a scale pass per batch, and the result is
+    the exact sum all the same - with the same bits on a second run."""
+    n = 4_600_000
+    r = np.random.default_rng(31)
+    k = (np.arange(n) % 7).astype(np.int64)
+    v = r.uniform(-1e-3, 1e-3, n)
+    v[4_400_000:] = r.uniform(-1, 1, n - 4_400_000) * 1e18
+    C = qe.ColumnExpression
+
+    def run():
+        batch = qe.Batch.from_numpy(det_ctx, [k, v])
+        plan = qe.AggregateExec([qe.ScanExec(det_ctx, [batch])], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None)])
+        return _sorted_columns(list(plan.execute())[0])
+    one, two = run(), run()
+    assert np.array_equal(one[1].view(np.uint64), two[1].view(np.uint64))
+    for key, s, cnt in zip(one[0].tolist(), one[1].tolist(), one[2].tolist()):
+        xs = v[k == key]
+        assert cnt == len(xs)
+        e, mag = math.fsum(xs.tolist()), float(np.abs(xs).sum())
+        assert abs(s - e) <= REL * mag * 1e-3, (key, s, e)
+
+
+def test_streaming_protocol_starts_over_too(qe, det_ctx):
+    """qe_agg_update / qe_agg_finalize with batches whose values grow past the first batch's scale: finalize folds the
+    batches in again with exact scales."""
+    r = np.random.default_rng(37)
+    parts = [(r.integers(0, 20, 30_000).astype(np.int64), r.uniform(-1, 1, 30_000) * s) for s in (1.0, 1e30, 1e-5)]
+    C = qe.ColumnExpression
+    st = qe.AggregationState(det_ctx, [C(0)], [qe.SumExpression(C(1)), qe.AvgExpression(C(1))])
+    for kk, vv in parts:
+        st.accumulate(qe.Batch.from_numpy(det_ctx, [kk, vv]))
+    out = _sorted_columns(st.final_value())
+    st.close()
+    k = np.concatenate([p[0] for p in parts])
+    v = np.concatenate([p[1] for p in parts])
+    for key, s in zip(out[0].tolist(), out[1].tolist()):
+        xs = v[k == key].tolist()
+        e, mag = math.fsum(xs), math.fsum(abs(x) for x in xs)
+        assert abs(s - e) <= REL * mag * 1e-3
