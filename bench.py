@@ -555,8 +555,19 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
     def c2():
         sel = qe.SelectionExec([qe.ScanExec(ctx, b2)], qe.GtExpression(C(2), qe.LiteralFloatExpression(0.5)))
         return list(qe.ProjectionExec([sel], [qe.AddExpression(C(0), qe.MulExpression(C(1), C(2)))]).execute())[0]
+    # QE_FLAG_DEFERRED_ROW_COUNT: the batch comes back with the kernel queued and its row count on the way to pinned memory
+    # (read when somebody asks: here after the timed steps), so the host queues step after step the way the reference's
+    # SelectionIterator streams batches (physical_plan/mod.rs:205-229)
+    ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_DEFERRED_ROW_COUNT)
     dt, prof, out = timed(ctx, torch, c2, 5, 2)
-    entry("C2_filter_project_100M", r2, dt, prof, "qe_filter", BYTES_PER_ROW["c2"], 1, {"rows_out": out.num_rows})
+    entry("C2_filter_project_100M", r2, dt, prof, "qe_filter", BYTES_PER_ROW["c2"], 1,
+          {"rows_out": out.num_rows, "host_sync": "none inside a step (deferred row count)"})
+    ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP)
+    del out
+    # the same under the default flags: every batch's row count is read back before it is handed over
+    dt, prof, out = timed(ctx, torch, c2, 5, 2)
+    entry("C2_filter_project_100M_default_flags", r2, dt, prof, "qe_filter", BYTES_PER_ROW["c2"], 1,
+          {"rows_out": out.num_rows, "host_sync": "per batch (row count read back)"})
     del out
 
     # C3: SUM(fare), COUNT(*) GROUP BY passenger_count-style key, 500 M rows (key column + one float64)
@@ -621,9 +632,15 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
     # The one workload the reference's own tests pin: test_filter (tests/mod.rs:138-188) - Scan -> Selection(gender ==
     # "Female"), all 13 columns of userdata.parquet kept (10 of them Utf8) - at 100 M rows: the fixture's 1000 rows
     # repeated, in batches of 10 M rows (Utf8Array<i32> offsets bound a batch's bytes per column to 2 GiB).
-    ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_JIT_SYNC)  # the predicate's kernel is compiled during the warm-up step
+    # (QE_FLAG_JIT_SYNC: the predicate's kernel is compiled during the warm-up step; deferred row count: no batch waits for
+    # the device, a batch's rows are read when the batch two after it has been queued)
+    ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_JIT_SYNC | qe.FLAG_DEFERRED_ROW_COUNT)
     try:
         res["utf8_test_filter_shape_100M"] = utf8_filter_config(qe, ctx, torch, dev)
+        res["utf8_test_filter_shape_100M"]["host_sync"] = "none per batch (deferred row count: rows and byte totals read two batches later)"
+        ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_JIT_SYNC)
+        res["utf8_test_filter_shape_100M_default_flags"] = utf8_filter_config(qe, ctx, torch, dev)
+        res["utf8_test_filter_shape_100M_default_flags"]["host_sync"] = "two per batch (row count, byte totals)"
     except FileNotFoundError as e:
         res["utf8_test_filter_shape_100M"] = {"skipped": str(e)}
     ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP)
@@ -678,16 +695,28 @@ def utf8_filter_config(qe, ctx, torch, dev, repeats=10_000, n_batches=10):
     batches = [qe.Batch.from_device_columns(ctx, cols, keepalive=keep) for _ in range(n_batches)]  # the same buffers, scanned n_batches times
     gender = USERDATA_COLUMNS.index("gender")
 
-    def plan():
+    def plan(with_bytes=False):
         sel = qe.SelectionExec([qe.ScanExec(ctx, batches)], qe.EqExpression(qe.ColumnExpression(gender), qe.LiteralStringExpression("Female")))
-        n_out, out_bytes = 0, 0
-        for out in sel.execute():  # one output batch per input batch, dropped as the next one comes
+        from collections import deque
+        n_out, out_bytes, window = 0, 0, deque()
+
+        def account(out):
+            nonlocal n_out, out_bytes
             n_out += out.num_rows
-            for i in range(out.num_columns):
+            # (a column's descriptor carries its null count, counted on demand by a kernel the host waits for: the sizes
+            # of the output buffers are therefore taken in a pass of their own, outside the timed steps)
+            for i in range(out.num_columns if with_bytes else 0):
                 dsc = out.column_desc(i)
                 out_bytes += dsc.values_bytes + (4 * (dsc.length + 1) if dsc.offsets else 0) + (dsc.length // 8 if dsc.validity else 0)
+        for out in sel.execute():  # one output batch per input batch; a batch is looked at (and dropped) two batches later
+            window.append(out)
+            if len(window) > 2:
+                account(window.popleft())
+        while window:
+            account(window.popleft())
         return n_out, out_bytes
-    dt, prof, (n_out, out_bytes) = timed(ctx, torch, plan, 2, 1)
+    dt, prof, (n_out, _) = timed(ctx, torch, plan, 2, 1)
+    _, out_bytes = plan(with_bytes=True)
     total_rows = rows * n_batches
     moved = in_bytes * n_batches + out_bytes
     return {"rows": total_rows, "rows_out": n_out, "columns": 13, "utf8_columns": 10, "rows_per_s": total_rows / dt, "ms_per_step": dt * 1e3,

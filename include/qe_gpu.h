@@ -135,7 +135,23 @@ enum {
    * result is within rows * 2^-87 * max|value| of the exact sum.  Costs the
    * extra pass, four integer accumulators per sum and a wait per batch; at most
    * 2^31 rows per aggregate. */
-  QE_FLAG_DETERMINISTIC_SUM = 16
+  QE_FLAG_DETERMINISTIC_SUM = 16,
+  /* A Selection (with the Projection fused onto it) hands its output batch back
+   * without waiting for the device to report how many rows were selected: the
+   * kernels are queued, the batch's buffers are sized for every input row (a
+   * string column's bytes by its source column's), and the row count travels
+   * to pinned host memory behind them.  The batch takes its final shape - row
+   * count, column lengths, string byte totals - the first time anything asks
+   * for it: qe_batch_num_rows / qe_batch_column / qe_batch_to_host, or any call
+   * that consumes the batch, wait for that one copy (not for the stream) if it
+   * has not arrived.  qe_iter_next then never synchronises, so the host can
+   * queue batch after batch the way the reference's SelectionIterator::next
+   * streams them (physical_plan/mod.rs:205-229); device-side consumers on the
+   * context's stream need no wait at all.  A look-back that timed out is
+   * reported (QE_ERR_INTERNAL) by that first use instead of by qe_iter_next.
+   * Selections that need the count on the host to go on - a string literal as
+   * an output column, more outputs than one launch takes - wait as before. */
+  QE_FLAG_DEFERRED_ROW_COUNT = 32
 };
 
 typedef struct qe_context qe_context;

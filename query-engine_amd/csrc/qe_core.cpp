@@ -80,9 +80,75 @@ void Context::prof_end(const char *actual_name) {
   QE_HIP(hipEventRecord(launches.back().stop, stream));
 }
 
+unsigned long long *Context::take_pending_words() {
+  if (pending_free.empty()) {
+    bind();
+    constexpr int BLOCKS = 64;
+    unsigned long long *slab = nullptr;
+    QE_HIP(hipHostMalloc((void **)&slab, (size_t)BLOCKS * PENDING_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+    pending_slabs.push_back(slab);
+    for (int i = 0; i < BLOCKS; ++i) pending_free.push_back(slab + (size_t)i * PENDING_WORDS);
+  }
+  unsigned long long *w = pending_free.back();
+  pending_free.pop_back();
+  return w;
+}
+
+hipEvent_t Context::take_pending_event() {
+  if (!pending_events.empty()) {
+    hipEvent_t e = pending_events.back();
+    pending_events.pop_back();
+    return e;
+  }
+  bind();
+  hipEvent_t e = nullptr;
+  QE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return e;
+}
+
+void PendingRows::wait() {
+  if (waited) return;
+  QE_HIP(hipEventSynchronize(ready));
+  waited = true;
+}
+
+PendingRows::~PendingRows() {
+  if (!ctx_ref) return;
+  // (the copy into the words may still be queued: the block is handed out again only to a copy queued later on the
+  // same stream, and nobody reads this one's any more)
+  if (host) ctx_ref->pending_free.push_back(host);
+  if (ready) ctx_ref->pending_events.push_back(ready);
+}
+
+void batch_settle(Batch &b) {
+  if (!b.pending) return;
+  std::shared_ptr<PendingRows> p = b.pending;
+  p->wait();
+  b.pending.reset();
+  if (p->host[2] != 0) fail(QE_ERR_INTERNAL, "filter look-back timed out");
+  const int64_t m = (int64_t)p->host[1];
+  b.rows = m;
+  for (size_t i = 0; i < b.cols.size(); ++i) {
+    Column &c = b.cols[i];
+    c.length = m;
+    const int slot = i < p->utf8_slot.size() ? p->utf8_slot[i] : -1;
+    if (c.type == QE_TYPE_UTF8 && slot >= 0) {
+      const unsigned long long *w = p->host + 4 + 4 * slot;
+      if (w[2] != 0) fail(QE_ERR_INTERNAL, "string gather look-back timed out");
+      c.values_bytes = (int64_t)w[1];
+    } else if (c.type == QE_TYPE_BOOLEAN) {
+      c.values_bytes = (m + 7) / 8;
+    } else if (type_width(c.type)) {
+      c.values_bytes = m * type_width(c.type);
+    }
+  }
+}
+
 Context::~Context() {
   (void)hipSetDevice(device);
   (void)hipStreamSynchronize(stream);
+  for (hipEvent_t e : pending_events) (void)hipEventDestroy(e);
+  for (unsigned long long *slab : pending_slabs) (void)hipHostFree(slab);
   for (auto &r : launches) {
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);

@@ -54,6 +54,15 @@ struct Context : std::enable_shared_from_this<Context> {
   unsigned long long *deferred_sink();  // the device word
   void check_deferred();                // with the stream idle: fails if any such aggregate overflowed
   unsigned long long *host_counters = nullptr;  // pinned mirror
+  // Selections that returned before the device was done (QE_FLAG_DEFERRED_ROW_COUNT): each output batch owns a block of
+  // pinned words its row count (and its string columns' byte totals) travel to, and an event recorded behind that copy.
+  // Blocks and events are handed out from free lists (pinned memory comes in slabs); a batch gives them back when the
+  // last copy of it goes.
+  static constexpr int PENDING_WORDS = 128;
+  std::vector<unsigned long long *> pending_free, pending_slabs;
+  std::vector<hipEvent_t> pending_events;
+  unsigned long long *take_pending_words();
+  hipEvent_t take_pending_event();
   // profiling
   bool profiling = false;
   int64_t profile_min_rows = 0;  // > 0: only launches over at least this many rows are timed
@@ -108,11 +117,27 @@ struct Column {
   const int32_t *offsets_ptr() const { return offsets ? (const int32_t *)offsets->ptr : nullptr; }
 };
 
+// The row count of a Selection's output that the host has not read yet (QE_FLAG_DEFERRED_ROW_COUNT): the batch's
+// columns are sized for every input row, `rows` is that bound, and the words the device copies to `host` behind the
+// kernels say how many rows (and, per string column, bytes) there really are.
+struct PendingRows {
+  std::shared_ptr<Context> ctx_ref;
+  unsigned long long *host = nullptr;  // [0..2] the filter's ticket / rows / look-back error, then four words per string column (ticket, bytes, error, -)
+  hipEvent_t ready = nullptr;          // recorded behind the last copy into `host`
+  std::vector<int> utf8_slot;          // per output column: its block of four words, or -1
+  bool waited = false;
+  void wait();  // returns once the words have arrived
+  ~PendingRows();
+};
+
 struct Batch {
   Context *ctx = nullptr;
   std::vector<Column> cols;
   int64_t rows = 0;
+  std::shared_ptr<PendingRows> pending;  // set: `rows` and the columns' lengths are upper bounds until batch_settle()
 };
+// Waits for a pending row count and gives the batch its final shape (no-op for any other batch).
+void batch_settle(Batch &b);
 
 size_t bitmap_bytes(int64_t n);   // padded to whole 32-byte groups
 int type_width(int type);         // bytes per value of a fixed-width type (0 otherwise)

@@ -135,7 +135,11 @@ static Column utf8_broadcast_column(Context *ctx, const std::string &s, int64_t 
 
 // Rows idx[0..m) of several utf8 columns.  The offsets of a group of (up to sixteen) columns are computed first, their byte
 // totals come back with one synchronisation, then the bytes are copied: the host waits once per group, not once per column.
-static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<const Column *> &srcs, const int32_t *idx, int64_t m) {
+// With `pending` the host does not wait at all: `m` is then only a bound (the batch's rows), the kernels read the
+// number of rows from `m_dev` (the word the filter kernel left it in), every output is sized for the bound - the bytes by
+// the source column's - and the byte totals travel to the pending batch's pinned words (from block `first_slot` on).
+static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<const Column *> &srcs, const int32_t *idx, int64_t m,
+                                               const unsigned long long *m_dev = nullptr, PendingRows *pending = nullptr, int first_slot = 0) {
   // a column's control block: ticket, byte total, look-back error, one word of padding - the head of a FilterScratch,
   // of which the offsets kernel touches nothing else
   constexpr size_t GROUP = UTF8_GATHER_MAX_COLS, FIRST_WORD = 64, CONTROL_WORDS = 4, CONTROL_BYTES = CONTROL_WORDS * sizeof(unsigned long long);
@@ -189,26 +193,36 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
       g.out_validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
       g.control = (char *)scratch->ptr + (j - g0) * CONTROL_BYTES;
       g.status = (char *)scratch->ptr + (cols * CONTROL_BYTES + 63) / 64 * 64 + (j - g0) * status_bytes;
+      if (pending) {
+        // no selection keeps more bytes than the column has
+        c.values_bytes = std::max<int64_t>(src.values_bytes, 0);
+        c.values = device_buffer(ctx, (size_t)c.values_bytes + 16);
+        g.out_bytes = (uint8_t *)c.values->ptr;
+      }
     }
     if (m <= 0) continue;
     // lengths by row id, scanned into offsets, in one pass over all columns of the group; offs[m] = a column's byte total
     ctx->prof_begin("qe_utf8_gather_offsets_kernel");
-    QE_HIP(launch_utf8_gather_offsets(launch, idx, m, ctx->dev.cus, ctx->stream));
+    QE_HIP(launch_utf8_gather_offsets(launch, idx, m, m_dev, ctx->dev.cus, ctx->stream));
     ctx->prof_end();
-    QE_HIP(hipMemcpyAsync(ctx->host_counters + FIRST_WORD, scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->sync();  // (the scratch block is done with here too)
-    for (size_t j = g0; j < g1; ++j) {
-      Column &c = out[j];
-      const unsigned long long *w = ctx->host_counters + FIRST_WORD + CONTROL_WORDS * (j - g0);
-      if (w[2] != 0) fail(QE_ERR_INTERNAL, "string gather look-back timed out");
-      if (w[1] > 2147483647ull) fail(QE_ERR_INVALID_ARGUMENT, "the selected strings of one column exceed 2^31 - 1 bytes: scan smaller batches");
-      const int32_t total = (int32_t)w[1];
-      c.values_bytes = total;
-      c.values = device_buffer(ctx, (size_t)total + 16);
-      launch.col[j - g0].out_bytes = (uint8_t *)c.values->ptr;
+    if (pending) {
+      QE_HIP(hipMemcpyAsync(pending->host + 4 + CONTROL_WORDS * (first_slot + g0), scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+      QE_HIP(hipMemcpyAsync(ctx->host_counters + FIRST_WORD, scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+      ctx->sync();  // (the scratch block is done with here too)
+      for (size_t j = g0; j < g1; ++j) {
+        Column &c = out[j];
+        const unsigned long long *w = ctx->host_counters + FIRST_WORD + CONTROL_WORDS * (j - g0);
+        if (w[2] != 0) fail(QE_ERR_INTERNAL, "string gather look-back timed out");
+        if (w[1] > 2147483647ull) fail(QE_ERR_INVALID_ARGUMENT, "the selected strings of one column exceed 2^31 - 1 bytes: scan smaller batches");
+        const int32_t total = (int32_t)w[1];
+        c.values_bytes = total;
+        c.values = device_buffer(ctx, (size_t)total + 16);
+        launch.col[j - g0].out_bytes = (uint8_t *)c.values->ptr;
+      }
     }
     ctx->prof_begin("qe_utf8_gather_bytes_kernel");
-    QE_HIP(launch_utf8_gather_bytes(launch, idx, m, ctx->stream));
+    QE_HIP(launch_utf8_gather_bytes(launch, idx, m, m_dev, ctx->stream));
     ctx->prof_end();
   }
   return out;
@@ -530,6 +544,18 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
   bool need_rowid = !utf8_cols.empty();
   size_t k = 0;
   bool first = true;
+  // QE_FLAG_DEFERRED_ROW_COUNT: the batch is handed back with the kernels queued and its row count on its way to pinned
+  // words of its own; nothing here waits for the device.  Not for what needs the count on the host to go on: string
+  // literals as outputs (their broadcast is sized by it), more string columns than the pinned block has room for,
+  // more outputs than one filter launch takes.
+  std::shared_ptr<PendingRows> pending;
+  if ((ctx->flags & QE_FLAG_DEFERRED_ROW_COUNT) && n > 0 && utf8_lits.empty() && 4 + 4 * utf8_cols.size() <= (size_t)Context::PENDING_WORDS) {
+    pending = std::make_shared<PendingRows>();
+    pending->ctx_ref = ctx->shared_from_this();
+    pending->host = ctx->take_pending_words();
+    pending->ready = ctx->take_pending_event();
+    pending->utf8_slot.assign(outs.size(), -1);
+  }
   while (first || k < vm_list.size()) {
     Compiler comp(ctx, &in);
     FilterArgs args{};
@@ -547,12 +573,18 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
       out.cols[i] = c;
     });
     if (!first && args.n_outs == 0) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Physical expression is too long for one kernel.");
+    // (outputs that take more than one pass: every pass's result words are checked against the first's on the host)
+    if (pending && k < vm_list.size()) pending.reset();
     args.scratch = scratch;
     QE_HIP(launch_filter_reset(scratch, n, ctx->stream));
     const char *kname = "qe_filter_kernel";
     ctx->prof_begin(kname, n);
     QE_HIP(launch_filter(args, ctx->dev, ctx->stream, &kname));
     ctx->prof_end(kname);
+    if (pending) {  // (one pass: see above)
+      first = false;
+      continue;
+    }
     // every pass runs the ticket / look-back protocol anew: each one's result words are read back (a look-back that
     // timed out leaves rows unwritten)
     QE_HIP(hipMemcpyAsync(ctx->host_counters, scratch, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -561,6 +593,24 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
     if (first) m = n > 0 ? (int64_t)ctx->host_counters[1] : 0;
     else if (n > 0 && (int64_t)ctx->host_counters[1] != m) fail(QE_ERR_INTERNAL, "filter passes selected different numbers of rows");
     first = false;
+  }
+  if (pending) {
+    // the filter's result words now; the string columns' byte totals follow from the gather below
+    QE_HIP(hipMemcpyAsync(pending->host, scratch, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    out.rows = n;
+    for (int i : vm_list) finish_fixed_column(out.cols[i], n);
+    if (!utf8_cols.empty()) {
+      std::vector<const Column *> srcs;
+      for (size_t j = 0; j < utf8_cols.size(); ++j) {
+        srcs.push_back(&in.cols[outs[utf8_cols[j]]->index]);
+        pending->utf8_slot[utf8_cols[j]] = (int)j;
+      }
+      std::vector<Column> got = utf8_gather_columns(ctx, srcs, (const int32_t *)rowid.values->ptr, n, &scratch->total, pending.get(), 0);
+      for (size_t j = 0; j < utf8_cols.size(); ++j) out.cols[utf8_cols[j]] = std::move(got[j]);
+    }
+    QE_HIP(hipEventRecord(pending->ready, ctx->stream));
+    out.pending = pending;
+    return out;
   }
   out.rows = m;
   for (int i : vm_list) finish_fixed_column(out.cols[i], m);
@@ -1977,9 +2027,16 @@ static qe_status write_string(const std::string &s, char *buf, int64_t buf_len, 
 
 qe_status qe_guarded(const std::function<void()> &f) { return guarded(f); }
 void qe_write_string(const std::string &s, char *buf, int64_t buf_len, int64_t *needed) { (void)write_string(s, buf, buf_len, needed); }
+// The batch behind a handle, in its final shape: a Selection's output whose row count the host has not read yet
+// (QE_FLAG_DEFERRED_ROW_COUNT) waits for it here, on its first use.
+static qe::Batch &settled(const qe_batch *batch) {
+  qe::Batch &b = const_cast<qe_batch *>(batch)->b;
+  qe::batch_settle(b);
+  return b;
+}
 const qe::Batch &qe_batch_ref(const qe_batch *batch) {
   if (!batch) fail(QE_ERR_INVALID_ARGUMENT, "batch is null");
-  return batch->b;
+  return settled(batch);
 }
 qe::Context *qe_context_ref(qe_context *ctx) { return &ctx->c; }
 std::shared_ptr<qe::Context> qe_context_share(qe_context *ctx) { return ctx->sp; }
@@ -2131,7 +2188,7 @@ qe_status qe_batch_import(qe_context *ctx, const qe_column *columns, int32_t n_c
 qe_status qe_batch_num_rows(const qe_batch *batch, int64_t *out) {
   return guarded([&] {
     QE_REQUIRE(batch && out, "bad arguments");
-    *out = batch->b.rows;
+    *out = settled(batch).rows;
   });
 }
 
@@ -2164,7 +2221,7 @@ qe_status qe_batch_column(const qe_batch *batch, int32_t index, qe_column *out) 
     QE_REQUIRE(batch && out, "bad arguments");
     if (index < 0 || index >= (int)batch->b.cols.size())
       fail(QE_ERR_EXCEEDING_BOUNDS, "The index `" + std::to_string(index) + "` is out of bounds.");
-    Column &c = const_cast<Column &>(batch->b.cols[index]);
+    Column &c = settled(batch).cols[index];
     if (c.null_count < 0) {
       // output bitmaps are produced by whole-word stores / atomics into padded buffers: count on demand
       bool word_ok = c.space == QE_MEM_HOST || c.validity->owned;
@@ -2224,7 +2281,7 @@ static qe_status copy_batch(qe_context *ctx, const qe_batch *batch, qe_batch **o
     ctx->c.bind();
     auto b = std::make_unique<qe_batch>();
     b->b.ctx = &ctx->c;
-    b->b.rows = batch->b.rows;
+    b->b.rows = settled(batch).rows;
     for (auto &c : batch->b.cols) b->b.cols.push_back(copy_column(&ctx->c, c, space));
     ctx->c.sync();
     *out = b.release();
@@ -2287,7 +2344,7 @@ qe_status qe_expr_evaluate(qe_context *ctx, const qe_expr *expr, const qe_batch 
   return guarded([&] {
     QE_REQUIRE(ctx && expr && batch && out, "bad arguments");
     std::memset(out, 0, sizeof(*out));
-    Schema schema = schema_of(batch->b);
+    Schema schema = schema_of(settled(batch));
     ExprPtr e = expr_normalize(expr->e, ctx->c.flags);
     int t = expr_type(e, schema);
     out->type = t;
@@ -2342,6 +2399,7 @@ qe_status qe_plan_scan_memory(qe_context *ctx, qe_batch *const *batches, int32_t
     p->ctx = &ctx->c;
     for (int i = 0; i < n_batches; ++i) {
       QE_REQUIRE(batches[i], "batch is null");
+      (void)settled(batches[i]);
       for (auto &c : batches[i]->b.cols)
         if (c.space != QE_MEM_DEVICE) fail(QE_ERR_INVALID_ARGUMENT, "scan batches must be device resident (qe_batch_to_device)");
       p->batches.push_back(batches[i]->b);
@@ -2496,6 +2554,7 @@ qe_status qe_agg_state_new(qe_context *ctx, qe_expr *const *group_exprs, int32_t
 qe_status qe_agg_update(qe_agg_state *state, const qe_batch *batch) {
   return guarded([&] {
     QE_REQUIRE(state && batch, "bad arguments");
+    (void)settled(batch);
     for (auto &c : batch->b.cols)
       if (c.space != QE_MEM_DEVICE) fail(QE_ERR_INVALID_ARGUMENT, "batches must be device resident (qe_batch_to_device)");
     if (!state->started) {
@@ -2610,7 +2669,7 @@ qe_status qe_selection_noalloc(qe_context *ctx, const qe_batch *batch, const qe_
     *rows_out = 0;
     Context *c = &ctx->c;
     c->bind();
-    const int64_t n = batch->b.rows;
+    const int64_t n = settled(batch).rows;
     if (n > NOALLOC_MAX_ROWS)
       fail(QE_ERR_INVALID_ARGUMENT, "qe_selection_noalloc: " + std::to_string(n) + " rows exceed the maximum of " +
                                         std::to_string(NOALLOC_MAX_ROWS) + " (QE_NOALLOC_MAX_ROWS) its fixed scratch array serves");

@@ -85,9 +85,10 @@ struct Utf8GatherCols {
 };
 size_t utf8_gather_offsets_status_bytes(int64_t m);
 // out_offsets[0..m] and the validity bits of every column.
-hipError_t launch_utf8_gather_offsets(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, int cus, hipStream_t stream);
+// `m_dev` (may be null): where the device holds the number of rows; `m` is then only a bound on it (grids and buffers are sized by it).
+hipError_t launch_utf8_gather_offsets(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, const unsigned long long *m_dev, int cus, hipStream_t stream);
 // The bytes, once out_offsets are there and out_bytes has been sized from the totals.
-hipError_t launch_utf8_gather_bytes(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, hipStream_t stream);
+hipError_t launch_utf8_gather_bytes(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, const unsigned long long *m_dev, hipStream_t stream);
 // Gather of strings by global row number over several source columns (group-by output keys).
 // Pass out_lengths to get the lengths (first pass), dst_offsets + dst_bytes to copy the bytes.
 struct Utf8Source {

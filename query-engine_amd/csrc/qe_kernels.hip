@@ -868,8 +868,16 @@ __global__ void qe_gather_rows_fixed_kernel(const FixedSource *sources, int n_so
 struct alignas(16) I32x4 { int32_t a, b, c, d; };
 constexpr int OFFSETS_THREADS = 1024, OFFSETS_TILE_MIN = 4096;  // (the status array is sized for the smallest tile)
 template <int R>  // rows a lane, consecutive: 4, 8 or 16 (measured: 4 and 8 alike, 16 much slower)
-__global__ __launch_bounds__(OFFSETS_THREADS) void qe_utf8_gather_offsets_kernel(const Utf8GatherCols C, const int32_t *idx, int64_t m, int64_t n_tiles) {
+__global__ __launch_bounds__(OFFSETS_THREADS) void qe_utf8_gather_offsets_kernel(const Utf8GatherCols C, const int32_t *idx, int64_t m_bound,
+                                                                                 const unsigned long long *m_dev) {
   constexpr int OFFSETS_TILE = OFFSETS_THREADS * R;
+  // the number of rows: the host's, or - when the host has not waited for it - the word the filter kernel left it in
+  const int64_t m = m_dev ? (int64_t)__hip_atomic_load(m_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : m_bound;
+  const int64_t n_tiles = (m + OFFSETS_TILE - 1) / OFFSETS_TILE;
+  if (m <= 0) {  // no tile ever writes offsets[m] = offsets[0] then
+    if (blockIdx.x == 0 && (int)threadIdx.x < C.n) C.col[threadIdx.x].out_offsets[0] = 0;
+    return;
+  }
   constexpr uint32_t LANES_A_WORD = 32 / R;  // lanes whose rows share one 32-row validity word
   __shared__ int32_t s_wave[OFFSETS_THREADS / 64];
   __shared__ unsigned long long s_tile, s_base;
@@ -1053,7 +1061,9 @@ __device__ __forceinline__ uint32_t utf8_gather_dword(const int32_t *sd, const i
 }
 
 // Column blockIdx.y of the launch.  (src_total, the bytes of the source column: a 16-byte fetch must end inside them.)
-__global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel(const Utf8GatherCols C, const int32_t *idx, int64_t m) {
+__global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel(const Utf8GatherCols C, const int32_t *idx, int64_t m_bound,
+                                                                                 const unsigned long long *m_dev) {
+  const int64_t m = m_dev ? (int64_t)__hip_atomic_load(m_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : m_bound;
   const Utf8GatherCol &col = C.col[blockIdx.y];
   const int32_t *const src_offsets = col.src_offsets;
   const uint8_t *__restrict__ const src_bytes = col.src_bytes;
@@ -1561,7 +1571,7 @@ hipError_t launch_finalize(const FinalizeArgs &args, hipStream_t stream) {
 
 size_t utf8_gather_offsets_status_bytes(int64_t m) { return (size_t)((m + OFFSETS_TILE_MIN - 1) / OFFSETS_TILE_MIN) * sizeof(unsigned long long); }
 
-hipError_t launch_utf8_gather_offsets(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, int cus, hipStream_t stream) {
+hipError_t launch_utf8_gather_offsets(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, const unsigned long long *m_dev, int cus, hipStream_t stream) {
   if (m <= 0 || cols.n <= 0) return hipSuccess;
   if (cols.n > UTF8_GATHER_MAX_COLS || ((uintptr_t)idx & 15)) return hipErrorInvalidValue;
   for (int i = 0; i < cols.n; ++i)
@@ -1570,7 +1580,7 @@ hipError_t launch_utf8_gather_offsets(const Utf8GatherCols &cols, const int32_t 
   const int64_t tile = (int64_t)OFFSETS_THREADS * R, n_tiles = (m + tile - 1) / tile;
   const int64_t tickets = n_tiles * cols.n, resident = (int64_t)cus * 2;
   const int grid = (int)(tickets < resident ? tickets : resident);
-  hipLaunchKernelGGL(qe_utf8_gather_offsets_kernel<R>, dim3(grid), dim3(OFFSETS_THREADS), 0, stream, cols, idx, m, n_tiles);
+  hipLaunchKernelGGL(qe_utf8_gather_offsets_kernel<R>, dim3(grid), dim3(OFFSETS_THREADS), 0, stream, cols, idx, m, m_dev);
   return hipGetLastError();
 }
 
@@ -1599,10 +1609,10 @@ hipError_t launch_exclusive_scan_i32(int32_t *data, int64_t n, int32_t *block_su
   return hipGetLastError();
 }
 
-hipError_t launch_utf8_gather_bytes(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, hipStream_t stream) {
+hipError_t launch_utf8_gather_bytes(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, const unsigned long long *m_dev, hipStream_t stream) {
   if (m <= 0 || cols.n <= 0) return hipSuccess;
   if (cols.n > UTF8_GATHER_MAX_COLS) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(qe_utf8_gather_bytes_kernel, dim3(grid_for(m, 256, 8192), cols.n), dim3(GATHER_WAVES * 64), 0, stream, cols, idx, m);
+  hipLaunchKernelGGL(qe_utf8_gather_bytes_kernel, dim3(grid_for(m, 256, 8192), cols.n), dim3(GATHER_WAVES * 64), 0, stream, cols, idx, m, m_dev);
   return hipGetLastError();
 }
 
