@@ -151,7 +151,19 @@ enum {
    * reported (QE_ERR_INTERNAL) by that first use instead of by qe_iter_next.
    * Selections that need the count on the host to go on - a string literal as
    * an output column, more outputs than one launch takes - wait as before. */
-  QE_FLAG_DEFERRED_ROW_COUNT = 32
+  QE_FLAG_DEFERRED_ROW_COUNT = 32,
+  /* Group keys that do not fit the 64-bit packed key (a string, a string next to
+   * other keys, more than 64 bits of integers) are identified by a 64-bit hash
+   * of the tuple.  By default the aggregate then checks, once every batch is
+   * in, that every row's key columns equal those of its group's representative
+   * row, and fails with QE_ERR_INTERNAL if two distinct keys were merged.  With
+   * this flag the check is left out and such groups are identified by their
+   * hash alone, as the reference identifies every group
+   * (physical_plan/mod.rs:310-358). */
+  QE_FLAG_HASH_ONLY_GROUP_IDENTITY = 64,
+  /* Testing only: the tuple hash above is taken modulo 5, so that distinct keys
+   * do collide and the check has something to find. */
+  QE_FLAG_DEBUG_WEAK_KEY_HASH = 128
 };
 
 typedef struct qe_context qe_context;

@@ -42,6 +42,8 @@ FLAG_JIT_SYNC = 4
 FLAG_DEFERRED_GROUP_COUNT = 8
 FLAG_DETERMINISTIC_SUM = 16
 FLAG_DEFERRED_ROW_COUNT = 32
+FLAG_HASH_ONLY_GROUP_IDENTITY = 64
+FLAG_DEBUG_WEAK_KEY_HASH = 128
 
 _NP_OF_TYPE = {TYPE_INT32: np.int32, TYPE_INT64: np.int64, TYPE_FLOAT64: np.float64, TYPE_TIMESTAMP_NS: np.int64}
 _TYPE_OF_NP = {np.dtype(np.int32): TYPE_INT32, np.dtype(np.int64): TYPE_INT64, np.dtype(np.float64): TYPE_FLOAT64,

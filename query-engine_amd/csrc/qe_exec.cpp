@@ -759,6 +759,7 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
           fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "Group keys identified by a hash of the tuple must be plain columns.");
         h = make_key_hash(h, e);
       }
+      if (flags & QE_FLAG_DEBUG_WEAK_KEY_HASH) h = make_binary(QE_OP_MOD, h, make_lit_i64(5));  // (testing: distinct keys collide)
       VmKey k{};
       k.type = (uint8_t)QE_TYPE_INT64;
       k.shift = 0;
@@ -787,7 +788,7 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
       k.shift = 0;
       k.bits = 64;
       spec.keys.push_back(k);
-      spec.key_exprs.push_back(make_hash_utf8(e));
+      spec.key_exprs.push_back((flags & QE_FLAG_DEBUG_WEAK_KEY_HASH) ? make_binary(QE_OP_MOD, make_hash_utf8(e), make_lit_i64(5)) : make_hash_utf8(e));
       int a = add_acc(spec, ACC_MIN, QE_TYPE_INT64, false, make_rowid(row_base));
       spec.key_gathers.push_back(AggSpec::KeyGather{(int)spec.outs.size(), e->index, QE_TYPE_UTF8});
       spec.outs.push_back(fin(FIN_ACC_ORD, QE_TYPE_INT64, a, a, CNT_ROWS, NULL_NEVER));
@@ -1180,6 +1181,15 @@ struct AggState {
   AggTable table{};
   BufferPtr table_buf;
   std::vector<std::vector<Utf8KeySource>> key_sources;  // per gathered key column: its source in every batch
+  // Groups identified by a hash of their key tuple: what it takes to compare every row's key with its group's
+  // representative's once all batches are in (verify_hashed_keys) - per batch the columns as the kernel saw them
+  // (temporaries of computed keys included), the predicate, the hash expression, the first row's number.
+  struct VerifyItem {
+    Batch in;
+    ExprPtr pred, hash;
+    int64_t row_base;
+  };
+  std::vector<VerifyItem> verify_items;
   int64_t row_base = 0;
   int deferred_finishes = 0;
   BufferPtr deferred_block;  // output block of the deferred mode, cleared by the table's init launch
@@ -1251,6 +1261,7 @@ struct AggState {
     table = AggTable{};
     table_buf.reset();
     key_sources.clear();
+    verify_items.clear();
     row_base = 0;
     fix_scale.clear();
     fix_rows = 0;
@@ -1413,6 +1424,8 @@ struct AggState {
                                    any_fix && fix_overflow ? (uint64_t)(uintptr_t)fix_overflow->ptr : 0);
     key_sources.resize(bspec.key_gathers.size());
     for (size_t i = 0; i < bspec.key_gathers.size(); ++i) key_sources[i].push_back(Utf8KeySource{in.cols[bspec.key_gathers[i].col], row_base});
+    if (!bspec.key_gathers.empty() && !(ctx->flags & QE_FLAG_HASH_ONLY_GROUP_IDENTITY))
+      verify_items.push_back(VerifyItem{in, pred_n, bspec.key_exprs[0], row_base});
     row_base += in.rows;
     if (!have_table) {
       spec = bspec;
@@ -1587,6 +1600,62 @@ struct AggState {
     return true;
   }
 
+  // Group identity by hash, checked: every selected row's key columns against those of the representative row of the
+  // group its hash names.  Any difference means two distinct key tuples share one 64-bit hash and were merged - what the
+  // reference does silently (physical_plan/mod.rs:310-358: groups are identified by the sum of column hashes alone).
+  void verify_hashed_keys() {
+    if (verify_items.empty() || spec.key_gathers.empty()) return;
+    const int n_keys = (int)spec.key_gathers.size(), n_sources = (int)verify_items.size();
+    if (n_keys > VERIFY_MAX_KEYS) fail(QE_ERR_INTERNAL, "too many key columns to verify");
+    std::vector<KeyColumnSource> table((size_t)n_keys * n_sources);
+    for (int k = 0; k < n_keys; ++k)
+      for (int b = 0; b < n_sources; ++b) {
+        const Utf8KeySource &src = key_sources[(size_t)k][(size_t)b];
+        table[(size_t)k * n_sources + b] = KeyColumnSource{src.col.values_ptr(), src.col.offsets_ptr(), src.first_row};
+      }
+    BufferPtr dev_table = device_buffer(ctx, table.size() * sizeof(KeyColumnSource) + 16);
+    QE_HIP(hipMemcpyAsync(dev_table->ptr, table.data(), table.size() * sizeof(KeyColumnSource), hipMemcpyHostToDevice, ctx->stream));
+    ensure_counters(ctx);
+    unsigned long long *mismatches = ctx->counters + 42;
+    QE_HIP(hipMemsetAsync(mismatches, 0, sizeof(unsigned long long), ctx->stream));
+    const uint32_t saved_flags = ctx->flags;
+    ctx->flags &= ~(uint32_t)QE_FLAG_DEFERRED_ROW_COUNT;  // the launches below are sized by the row count
+    try {
+      for (int b = 0; b < n_sources; ++b) {
+        const VerifyItem &it = verify_items[(size_t)b];
+        if (it.in.rows == 0) continue;
+        // the rows the aggregate kept, by number, with their tuple hashes (a row with a null key has a null hash)
+        Batch t = run_pipeline_typed(ctx, it.in, {make_rowid(it.row_base), it.hash}, it.pred ? it.pred : make_lit_bool(true));
+        VerifyArgs va{};
+        va.table = table_args();
+        va.rep_acc = spec.outs[(size_t)spec.key_gathers[0].out].a;
+        va.row_ids = (const int64_t *)t.cols[0].values_ptr();
+        va.hashes = (const unsigned long long *)t.cols[1].values_ptr();
+        va.hash_validity = (const uint32_t *)t.cols[1].validity_ptr();
+        va.m = t.rows;
+        va.row_base = it.row_base;
+        va.this_source = b;
+        va.n_keys = n_keys;
+        va.n_sources = n_sources;
+        for (int k = 0; k < n_keys; ++k) va.key_type[k] = spec.key_gathers[(size_t)k].type;
+        va.sources = (const KeyColumnSource *)dev_table->ptr;
+        va.mismatches = mismatches;
+        ctx->prof_begin("qe_verify_group_keys_kernel");
+        QE_HIP(launch_verify_group_keys(va, ctx->stream));
+        ctx->prof_end();
+      }
+    } catch (...) {
+      ctx->flags = saved_flags;
+      throw;
+    }
+    ctx->flags = saved_flags;
+    QE_HIP(hipMemcpyAsync(ctx->host_counters + 42, mismatches, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();  // (`table` on the host has been read, the temporaries of the loop are done with)
+    if (ctx->host_counters[42] != 0)
+      fail(QE_ERR_INTERNAL, std::to_string(ctx->host_counters[42]) + " rows were grouped with a key that is not theirs: two distinct group keys share one 64-bit hash");
+  }
+  AggTable table_args() const { return table; }
+
   bool finish(Batch &result) {
     ctx->bind();
     if (!parts.empty()) return finish_parts(result);
@@ -1647,6 +1716,7 @@ struct AggState {
     }
     result.rows = (int64_t)n_groups;
     for (auto &c : result.cols) finish_fixed_column(c, (int64_t)n_groups);
+    verify_hashed_keys();
     for (size_t i = 0; i < spec.key_gathers.size(); ++i) {
       const AggSpec::KeyGather &kg = spec.key_gathers[i];
       const Column ids = result.cols[kg.out];  // representative row numbers; the buffer lives until the gather is done

@@ -105,6 +105,31 @@ struct FixedSource {
 };
 hipError_t launch_gather_rows_fixed(const FixedSource *sources, int n_sources, const int64_t *ids, int64_t m, int width, void *out,
                                     hipStream_t stream);
+// Key equality for groups that are identified by a 64-bit hash of their key tuple (string keys, wide tuples): every
+// selected row's key columns against those of its group's representative row (the row whose number the group's hidden
+// MIN(row number) accumulator holds).  The reference identifies groups by hash alone (physical_plan/mod.rs:310-358); two
+// distinct keys with one hash would merge silently.  One launch per scanned batch, after every batch has been folded in.
+constexpr int VERIFY_MAX_KEYS = 12;
+struct KeyColumnSource {  // one key column of one scanned batch
+  const void *values;     // fixed width: values (booleans bit-packed); utf8: bytes
+  const int32_t *offsets; // utf8 only
+  int64_t first_row;      // global row number of the batch's first row; batches in ascending order
+};
+struct VerifyArgs {
+  AggTable table;
+  int rep_acc;                       // the accumulator holding the order-preserving image of MIN(row number)
+  const int64_t *row_ids;            // the batch's selected rows (global row numbers) and their tuple hashes
+  const unsigned long long *hashes;
+  const uint32_t *hash_validity;     // null: every hash is valid (a row with a null key has none and belongs to no group)
+  int64_t m;
+  int64_t row_base;                  // global row number of this batch's first row
+  int this_source;                   // index of this batch among the sources
+  int n_keys, n_sources;
+  int key_type[VERIFY_MAX_KEYS];     // VmType (= QE_TYPE_*)
+  const KeyColumnSource *sources;    // [n_keys][n_sources]
+  unsigned long long *mismatches;    // += rows whose key differs from their group's representative's
+};
+hipError_t launch_verify_group_keys(const VerifyArgs &args, hipStream_t stream);
 // Broadcast one utf8 literal to `n` rows (scalar_to_array for Utf8, columnar_value.rs:40-50).
 hipError_t launch_utf8_broadcast(const uint8_t *lit, int32_t len, int64_t n, int32_t *out_offsets, uint8_t *out_bytes,
                                  hipStream_t stream);

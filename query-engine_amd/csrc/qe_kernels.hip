@@ -860,6 +860,65 @@ __global__ void qe_gather_rows_fixed_kernel(const FixedSource *sources, int n_so
   }
 }
 
+// A hashed group key's equality check: see VerifyArgs.  A thread to a selected row: the row's hash finds its group's slot
+// (read-only probe), the slot's MIN(row number) names the representative row, and the two rows' key columns are
+// compared value by value (strings: length, then bytes).
+__global__ __launch_bounds__(256) void qe_verify_group_keys_kernel(const VerifyArgs A) {
+  const AggTable &T = A.table;
+  unsigned long long bad = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < A.m; i += (int64_t)gridDim.x * blockDim.x) {
+    if (A.hash_validity && !((A.hash_validity[i >> 5] >> (i & 31)) & 1u)) continue;
+    const unsigned long long key = A.hashes[i];
+    int64_t slot = -1;
+    if (key == AGG_EMPTY_KEY) {
+      slot = (int64_t)T.cap;
+    } else {
+      const uint64_t mask = T.cap - 1;
+      uint64_t s = global_home(T, key, mix64(key));
+      for (uint64_t p = 0; p <= mask; ++p) {
+        const unsigned long long cur = T.keys[s];
+        if (cur == key) {
+          slot = (int64_t)s;
+          break;
+        }
+        if (cur == AGG_EMPTY_KEY) break;
+        s = (s + 1) & mask;
+      }
+    }
+    if (slot < 0) {  // a selected row whose group is not in the table: the table and the batches disagree
+      ++bad;
+      continue;
+    }
+    const int64_t rep = (int64_t)ord_inverse(T.acc[(size_t)A.rep_acc * T.stride + (size_t)slot], VT_I64);
+    const int64_t me = A.row_ids[i];
+    if (rep == me) continue;
+    int sb = A.n_sources - 1;
+    while (sb > 0 && A.sources[sb].first_row > rep) --sb;
+    const int64_t r1 = me - A.row_base, r2 = rep - A.sources[sb].first_row;
+    bool same = true;
+    for (int k = 0; k < A.n_keys && same; ++k) {
+      const KeyColumnSource &mine = A.sources[(size_t)k * A.n_sources + A.this_source], &theirs = A.sources[(size_t)k * A.n_sources + sb];
+      switch (A.key_type[k]) {
+        case VT_I32: same = ((const int32_t *)mine.values)[r1] == ((const int32_t *)theirs.values)[r2]; break;
+        case VT_I64: same = ((const int64_t *)mine.values)[r1] == ((const int64_t *)theirs.values)[r2]; break;
+        case VT_BOOL:
+          same = ((((const uint8_t *)mine.values)[r1 >> 3] >> (r1 & 7)) & 1u) == ((((const uint8_t *)theirs.values)[r2 >> 3] >> (r2 & 7)) & 1u);
+          break;
+        default: {  // utf8
+          const int32_t a0 = mine.offsets[r1], a1 = mine.offsets[r1 + 1], b0 = theirs.offsets[r2], b1 = theirs.offsets[r2 + 1];
+          same = a1 - a0 == b1 - b0;
+          const uint8_t *x = (const uint8_t *)mine.values + a0, *y = (const uint8_t *)theirs.values + b0;
+          for (int32_t b = 0; same && b < a1 - a0; ++b) same = x[b] == y[b];
+          break;
+        }
+      }
+    }
+    if (!same) ++bad;
+  }
+  bad = wave_sum_u64(bad);
+  if (lane_id() == 0 && bad) atomicAdd(A.mismatches, bad);
+}
+
 // ------------------------------------------------------------- utf8 helpers
 // Output offsets of the selected rows of a string column in one pass: lengths by row id, scanned within a tile of 4096
 // rows, the tile's first byte from a decoupled look-back over the tiles' byte counts (the filter's protocol: tiles
@@ -1628,6 +1687,13 @@ hipError_t launch_gather_rows_fixed(const FixedSource *sources, int n_sources, c
                                     hipStream_t stream) {
   if (m <= 0) return hipSuccess;
   hipLaunchKernelGGL(qe_gather_rows_fixed_kernel, dim3(grid_for(m, 256, 4096)), dim3(256), 0, stream, sources, n_sources, ids, m, width, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_verify_group_keys(const VerifyArgs &args, hipStream_t stream) {
+  if (args.m <= 0) return hipSuccess;
+  if (args.n_keys < 1 || args.n_keys > VERIFY_MAX_KEYS || args.n_sources < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(qe_verify_group_keys_kernel, dim3(grid_for(args.m, 256, 4096)), dim3(256), 0, stream, args);
   return hipGetLastError();
 }
 
