@@ -82,6 +82,100 @@ class StdoutToStderr:
         os.close(self.saved)
 
 
+SAMPLER_CODE = r"""
+import glob, json, os, sys, time
+out = open(sys.argv[1], "w", buffering=1)
+cards = []
+for c in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+    d = os.path.join(c, "device")
+    try:
+        if open(os.path.join(d, "vendor")).read().strip() != "0x1002":
+            continue
+    except OSError:
+        continue
+    hw = sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*")))
+    cards.append((os.path.basename(os.path.realpath(d)), d, hw[0] if hw else None))
+def starred(path):
+    try:
+        for line in open(path):
+            if line.rstrip().endswith("*"):
+                return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+def number(path):
+    try:
+        return int(open(path).read().strip())
+    except (OSError, ValueError):
+        return None
+period = float(sys.argv[2])
+while True:
+    t = time.time()
+    rec = {"t": t, "cards": {}}
+    for pci, d, hw in cards:
+        rec["cards"][pci] = {"sclk_mhz": starred(os.path.join(d, "pp_dpm_sclk")), "mclk_mhz": starred(os.path.join(d, "pp_dpm_mclk")),
+                             "power_uw": number(os.path.join(hw, "power1_input")) if hw else None,
+                             "temp_mc": number(os.path.join(hw, "temp2_input")) if hw else None,
+                             "busy_pct": number(os.path.join(d, "gpu_busy_percent"))}
+    out.write(json.dumps(rec) + "\n")
+    time.sleep(max(0.0, period - (time.time() - t)))
+"""
+
+
+class ClockSampler:
+    """Clocks, power and temperature of the GPUs read off sysfs two hundred times a second by a child process that is started
+    before this process has anything to do with a GPU (it touches no HIP: plain file reads of pp_dpm_sclk, pp_dpm_mclk and
+    the hwmon files), so that the samples that fall INSIDE the timed steps can be told from those before and after."""
+
+    def __init__(self, period=0.005):
+        import subprocess
+        import tempfile
+        self.path = os.path.join(tempfile.mkdtemp(prefix="qe_bench_clocks_"), "samples.jsonl")
+        try:
+            self.proc = subprocess.Popen([sys.executable, "-c", SAMPLER_CODE, self.path, str(period)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except OSError:
+            self.proc = None
+
+    def window(self, t0, t1, pci_bus_id=None):
+        """Summary of the samples taken between the wall-clock times t0 and t1 (time.time()), for the card on PCI bus
+        `pci_bus_id` (as torch reports it) or, when that is unknown, every card."""
+        out = {"source": "sysfs pp_dpm_sclk / pp_dpm_mclk / hwmon power1_input, temp2_input, sampled by a child process", "window_s": t1 - t0}
+        try:
+            recs = [json.loads(line) for line in open(self.path) if line.strip()]
+        except (OSError, ValueError) as e:
+            out["unavailable"] = str(e)[:200]
+            return out
+        inside = [r for r in recs if t0 <= r["t"] <= t1]
+        out["samples_total"], out["samples_in_window"] = len(recs), len(inside)
+        cards = {}
+        for r in inside:
+            for pci, v in r["cards"].items():
+                if pci_bus_id is not None:
+                    try:
+                        if int(pci.split(":")[1], 16) != int(pci_bus_id):
+                            continue
+                    except (ValueError, IndexError):
+                        pass
+                cards.setdefault(pci, []).append(v)
+        for pci, vs in cards.items():
+            summ = {}
+            for key, scale, name in (("sclk_mhz", 1, "sclk_mhz"), ("mclk_mhz", 1, "mclk_mhz"), ("power_uw", 1e-6, "power_w"), ("temp_mc", 1e-3, "temp_c"),
+                                     ("busy_pct", 1, "busy_pct")):
+                xs = [v[key] * scale for v in vs if v.get(key) is not None]
+                if xs:
+                    summ[name] = {"min": min(xs), "mean": sum(xs) / len(xs), "max": max(xs)}
+            out[pci] = summ
+        return out
+
+    def stop(self):
+        if self.proc is not None and self.proc.poll() is None:
+            self.proc.terminate()
+            try:
+                self.proc.wait(timeout=5)
+            except Exception:
+                self.proc.kill()
+
+
 def load_launcher():
     """query-engine_amd/launcher.py by path: importing the package would load the HIP library, and the ranks must be
     started before this process has anything to do with a GPU."""
@@ -103,6 +197,9 @@ def main():
     except launcher.LaunchError as e:
         print(f"bench.py: {e}", file=sys.stderr)
         sys.exit(2)
+    sampler = None
+    if rank == 0 and (launched or world == 1):
+        sampler = ClockSampler()  # a child process, started before this process touches a GPU
     import torch
     n_devices = torch.cuda.device_count()  # does not initialise the device
     if backend == "nccl" and n_devices < world:
@@ -299,16 +396,19 @@ def main():
         if ctx2 is not ctx:
             ctx2.synchronize()
 
+    wall_warm = time.time()
     for _ in range(args.warmup):
         result = step()
     ctx.profile(2)  # HIP events around the main kernel of every large launch only: event records on the small helper launches cost more than those launches
     barrier()
     ctx.profile_read()
+    wall0 = time.time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         result = step()
     barrier()
     dt = time.perf_counter() - t0
+    wall1 = time.time()
     state_after = gpu_state(local_rank) if rank == 0 else None
     prof = ctx.profile_read()
     ctx.profile(False)
@@ -390,6 +490,10 @@ def main():
     }
     out["config"]["topology"] = topology
     out["gpu_state_after_timed_steps"] = state_after
+    if sampler is not None:
+        # (the window is widened to the warm-up steps in front of the timed ones, which run the same kernels back to back)
+        out["gpu_state_during_timed_steps"] = sampler.window(wall_warm, wall1, getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None))
+        out["gpu_state_during_timed_steps"]["note"] = "window = warm-up steps + timed steps (%.0f ms of the %.0f ms are the timed steps)" % ((wall1 - wall0) * 1e3, (wall1 - wall_warm) * 1e3)
 
     cols = result.columns()
     real = np.asarray(cols[2].values) > 0  # deferred mode pads the result to the table's slots
@@ -406,11 +510,15 @@ def main():
         out["result_head"] = [[int(cols[0].values[i]), float(cols[1].values[i]), int(cols[2].values[i])] for i in order[:3]]
 
     if world == 1 and not args.no_extra:
+        global SAMPLER, SAMPLER_PCI
+        SAMPLER, SAMPLER_PCI = sampler, getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None)
         out["other_configs"] = extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args)
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_rows, seed)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if sampler is not None:
+        sampler.stop()
     if comm:
         comm.close()
     if multi:
@@ -462,17 +570,23 @@ def dominant_kernel(prof, prefix):
     return best
 
 
+SAMPLER, SAMPLER_PCI, LAST_WINDOW = None, None, None
+
+
 def timed(ctx, torch, fn, steps, warmup):
+    global LAST_WINDOW
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     ctx.profile(True)
     ctx.profile_read()
+    w0 = time.time()
     t0 = time.perf_counter()
     for _ in range(steps):
         r = fn()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    LAST_WINDOW = (w0, time.time())
     prof = ctx.profile_read()
     ctx.profile(False)
     return dt, prof, r
@@ -496,6 +610,9 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
              "kernels_ms_per_step": {kk: vv["ms"] / steps for kk, vv in prof.items()}}
         if extra:
             e.update(extra)
+        if SAMPLER is not None and LAST_WINDOW is not None:
+            w = SAMPLER.window(LAST_WINDOW[0], LAST_WINDOW[1], SAMPLER_PCI)
+            e["clocks_during_timed_steps"] = {k: v for k, v in w.items() if k not in ("source", "samples_total")}
         res[name] = e
 
     # The headline plan under the library's default flags (every aggregate waits for its group count and hands back

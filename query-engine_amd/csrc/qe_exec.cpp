@@ -1083,7 +1083,8 @@ static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &
     QE_HIP(launch_spill_count(args.spill, sp.waves, bits, blocks, cell, total, ctx->stream));
     ctx->prof_end();
   }
-  if (bits1 < bits) {
+  const bool onepass = spill_onepass_available(bits, args.spill.n_inputs);
+  if (bits1 < bits && !onepass) {
     QE_HIP(launch_spill_cells_level1(cell, cell1, bits, blocks, ctx->stream));
     QE_HIP(launch_exclusive_scan_i32(cell1, (int64_t)cells1, (int32_t *)scan_buf->ptr, ctx->stream));
   }
@@ -1096,9 +1097,21 @@ static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &
   if (m == 0) return;
   const uint64_t stride = ((uint64_t)m + 63) & ~63ull;  // rows between the value columns of a partitioned copy
   const uint32_t n_in = args.spill.n_inputs;
-  BufferPtr out_keys = device_buffer(ctx, stride * 8 + 64);
-  BufferPtr out_vals = device_buffer(ctx, stride * 8 * n_in + 64);
-  if (bits1 < bits) {
+  // One pass when the log has at most one value column: (key, value) pairs, written a whole 128-byte line at a time.
+  // Otherwise whole-KiB bursts per column, which takes two passes for more than 64 partitions.
+  BufferPtr out_keys, out_vals;
+  if (onepass) {
+    out_keys = device_buffer(ctx, stride * 16 + 256);
+    ctx->prof_begin("qe_spill_scatter_onepass_kernel");
+    QE_HIP(launch_spill_scatter_onepass(args.spill, sp.waves, bits, blocks, cell, out_keys->ptr, ctx->stream));
+    ctx->prof_end();
+  } else {
+    out_keys = device_buffer(ctx, stride * 8 + 64);
+    out_vals = device_buffer(ctx, stride * 8 * n_in + 64);
+  }
+  if (onepass) {
+    // (done above)
+  } else if (bits1 < bits) {
     BufferPtr mid_keys = device_buffer(ctx, stride * 8 + 64);
     BufferPtr mid_vals = device_buffer(ctx, stride * 8 * n_in + 64);
     ctx->prof_begin("qe_spill_scatter_kernel (level 1)");
@@ -1119,7 +1132,8 @@ static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &
   }
   PartArgs pa{};
   pa.keys = (const unsigned long long *)out_keys->ptr;
-  pa.vals = (const unsigned long long *)out_vals->ptr;
+  pa.vals = out_vals ? (const unsigned long long *)out_vals->ptr : nullptr;
+  pa.interleaved = onepass ? 1 : 0;
   pa.capacity = stride;
   pa.offsets = cell;
   pa.n_parts = 1 << bits;

@@ -48,6 +48,10 @@ hipError_t launch_spill_scatter(const AggSpill &sp, int n_segments, int level, i
                                 hipStream_t stream);
 uint32_t partitioned_lds_slots(int n_accs);
 hipError_t launch_aggregate_partitioned(const PartArgs &args, const DeviceInfo &dev, hipStream_t stream);
+// The scatter in one pass: (key, value) pairs of 16 bytes, written a whole 128-byte line at a time.  For logs with at most
+// one value column and at most 512 partitions; `dst_rows` holds 16 bytes per logged row.
+bool spill_onepass_available(int bits, uint32_t n_inputs);
+hipError_t launch_spill_scatter_onepass(const AggSpill &sp, int n_segments, int bits, int blocks, const int32_t *dst_cells, void *dst_rows, hipStream_t stream);
 // Workgroups launch_aggregate will use for these arguments (sizes the per-wave spill regions).
 int aggregate_grid(const AggArgs &args, const DeviceInfo &dev);
 

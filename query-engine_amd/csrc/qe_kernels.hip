@@ -234,7 +234,7 @@ __global__ __launch_bounds__(VM_BLOCK_THREADS, FULL ? 2 : 3) void qe_aggregate_k
 // the counts it made itself in the count pass.
 constexpr int PART_THREADS = 1024;
 constexpr int PART_MAX_BITS = 11;
-constexpr int SCATTER_MAX_STAGES = 64;
+constexpr int SCATTER_MAX_STAGES = 512;
 constexpr int SCATTER_ROWS = 4;       // rows per thread and round
 constexpr int SCATTER_MAX_INPUTS = 8;  // = SPILL_MAX_INPUTS of the host
 
@@ -479,6 +479,162 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_kernel(const Sc
   flush(1);
 }
 
+// ---- the one-pass scatter: every logged row to its partition in a single pass over the log
+// What a partitioning pass can afford is set by how its writes reach memory: a burst that covers whole 128-byte lines
+// is taken at close to the streaming rate however short it is (128-byte bursts of 16-byte stores at pseudo-random
+// places: 4.7 TB/s; tools/experiments/burst_probe.hip), one that starts or ends inside a line costs a read-modify-write
+// of that line (64-byte bursts shifted by 8 bytes: 0.8 TB/s).  So the rows are written as (key, value) pairs of 16
+// bytes, and a workgroup collects each partition's rows in a ring of 16 rows (two 128-byte lines) in LDS and writes a
+// line when it is complete: 512 partitions x 256 bytes = 128 KiB of LDS, one pass where the staging of whole KiB
+// bursts needed two.  A row's place in its partition is fixed when it arrives (a counter per partition), so a row that
+// finds its ring full is written straight to its place instead (a partial line, rare: rows arrive at half the rings'
+// capacity per round) and the line it belongs to is completed around it.  Only a cell's first and last line are partial.
+struct alignas(16) KeyVal { unsigned long long key, val; };
+constexpr int ONEPASS_RING = 16;      // rows a partition's ring holds (two lines of eight)
+constexpr int ONEPASS_ROWS = 2;       // rows per thread and round
+constexpr int ONEPASS_MAX_PARTS = 512;
+
+struct OnePassArgs {
+  AggSpill sp;               // the log: keys, one value column (or none), per-segment counts
+  int n_segments;
+  int bits;                  // partitions = 1 << bits
+  const int32_t *dst_cells;  // scanned cells [p * blocks + b]: first row of this workgroup's rows of partition p
+  KeyVal *dst;               // the partitioned rows
+  uint32_t n_inputs;         // 0 or 1
+};
+
+__global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_onepass_kernel(const OnePassArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lds_stage[];
+  const int P = 1 << A.bits;
+  KeyVal *ring = (KeyVal *)lds_stage;                                        // [P][ONEPASS_RING]
+  uint32_t *s_uw = (uint32_t *)(ring + (size_t)P * ONEPASS_RING);            // [P] rows arrived, counted from the line the cell starts in
+  uint32_t *s_ur = s_uw + P;                                                 // [P] first row not yet written (a multiple of 8)
+  uint32_t *s_valid = s_ur + P;                                              // [P] bit i: ring slot i holds a row
+  unsigned long long *s_dst0 = (unsigned long long *)(s_valid + P);          // [P] row index in dst of the ring's row 0 (cell start rounded down to a line)
+  uint32_t *s_ready = (uint32_t *)(s_dst0 + P);                              // [2 P] lines to write this round: partition << 1 | ring half
+  __shared__ uint32_t s_nready;
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  auto BAR = [&]() { lds_barrier(); };
+
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    const uint64_t base = (uint64_t)(uint32_t)A.dst_cells[(size_t)p * gridDim.x + blockIdx.x];
+    s_dst0[p] = base & ~7ull;
+    s_uw[p] = (uint32_t)(base & 7ull);
+    s_ur[p] = 0;
+    s_valid[p] = 0;
+  }
+  if (threadIdx.x == 0) s_nready = 0;
+  BAR();
+
+  // Writes the lines that are complete (every row of them has arrived); `all`: whatever has arrived, at the end.
+  auto flush = [&](bool all) {
+    for (int t = threadIdx.x; t < 2 * P; t += blockDim.x) {
+      const uint32_t p = (uint32_t)t >> 1, j = (uint32_t)t & 1u;
+      const uint32_t line0 = s_ur[p] + 8u * j, uw = s_uw[p];  // rows [line0, line0 + 8)
+      if (uw >= line0 + 8u || (all && uw > line0)) s_ready[atomicAdd(&s_nready, 1u)] = (p << 1) | ((line0 >> 3) & 1u);
+    }
+    BAR();
+    const uint32_t nready = s_nready;
+    for (uint32_t q = wave * 8u; q < nready; q += n_waves * 8u) {
+      const uint32_t e = q + (lane >> 3);
+      if (e < nready) {
+        const uint32_t entry = s_ready[e], p = entry >> 1, half = entry & 1u, r = lane & 7u;
+        const uint32_t slot = half * 8u + r;
+        if ((s_valid[p] >> slot) & 1u) {
+          // the slot's row number: the ring's window starts at s_ur (a multiple of 8); this half is its first or second line
+          const uint32_t ur = s_ur[p];
+          const uint32_t u = ((ur >> 3) & 1u) == half ? ur + r : ur + 8u + r;
+          A.dst[s_dst0[p] + u] = ring[(size_t)p * ONEPASS_RING + slot];
+        }
+      }
+    }
+    BAR();
+    // the written lines leave the window: two lines of one partition were both listed, the later one decides
+    for (uint32_t e = threadIdx.x; e < nready; e += blockDim.x) {
+      const uint32_t entry = s_ready[e], p = entry >> 1, half = entry & 1u;
+      const uint32_t ur = s_ur[p];
+      const uint32_t line_end = (((ur >> 3) & 1u) == half ? ur : ur + 8u) + 8u;
+      atomicMax(&s_ur[p], line_end);
+      atomicAnd(&s_valid[p], ~(0xffu << (8u * half)));
+    }
+    if (threadIdx.x == 0) s_nready = 0;
+    BAR();
+  };
+
+  struct Round {
+    int seg;
+    uint64_t first;
+    uint32_t cnt, i0;
+    bool valid;
+  };
+  const int seg_step = A.sp.seg_chunk ? 1 : (int)gridDim.x;
+  const int seg_end = A.sp.seg_chunk ? (int)((blockIdx.x + 1) * A.sp.seg_chunk) : A.n_segments;
+  auto open_segment = [&](Round &r) {
+    for (; r.seg < seg_end && r.seg < A.n_segments; r.seg += seg_step) {
+      r.cnt = A.sp.counts[r.seg];
+      r.first = (uint64_t)r.seg * A.sp.rows_per_wave;
+      if (r.cnt != 0) {
+        r.i0 = 0;
+        r.valid = true;
+        return;
+      }
+    }
+    r.valid = false;
+  };
+  auto advance = [&](Round &r) {
+    r.i0 += blockDim.x * (uint32_t)ONEPASS_ROWS;
+    if (r.i0 >= r.cnt) {
+      r.seg += seg_step;
+      open_segment(r);
+    }
+  };
+  auto fetch = [&](const Round &r, KeyVal (&row)[ONEPASS_ROWS]) {
+#pragma unroll
+    for (int k = 0; k < ONEPASS_ROWS; ++k) {
+      const uint32_t i = r.i0 + (uint32_t)k * blockDim.x + threadIdx.x;
+      row[k].key = 0;
+      row[k].val = 0;
+      if (r.valid && i < r.cnt) {
+        row[k].key = __builtin_nontemporal_load(&A.sp.keys[r.first + i]);
+        if (A.n_inputs > 0) row[k].val = __builtin_nontemporal_load(&A.sp.vals[r.first + i]);
+      }
+    }
+  };
+  Round cur;
+  cur.seg = A.sp.seg_chunk ? (int)(blockIdx.x * A.sp.seg_chunk) : (int)blockIdx.x;
+  cur.first = 0;
+  cur.cnt = 0;
+  cur.i0 = 0;
+  cur.valid = false;
+  open_segment(cur);
+  KeyVal row[ONEPASS_ROWS], nrow[ONEPASS_ROWS];
+  fetch(cur, row);
+  while (cur.valid) {  // uniform: barriers inside
+    Round nxt = cur;
+    advance(nxt);
+    fetch(nxt, nrow);  // a round ahead: the trip to memory overlaps this round's staging and barriers
+#pragma unroll
+    for (int k = 0; k < ONEPASS_ROWS; ++k) {
+      if (cur.i0 + (uint32_t)k * blockDim.x + threadIdx.x < cur.cnt) {
+        const uint32_t p = partition_of(row[k].key, A.bits);
+        const uint32_t u = atomicAdd(&s_uw[p], 1u);
+        if (u < s_ur[p] + (uint32_t)ONEPASS_RING) {
+          ring[(size_t)p * ONEPASS_RING + (u & (ONEPASS_RING - 1))] = row[k];
+          atomicOr(&s_valid[p], 1u << (u & (ONEPASS_RING - 1)));
+        } else {
+          A.dst[s_dst0[p] + u] = row[k];  // the ring is full: straight to its place
+        }
+      }
+    }
+    BAR();
+    flush(false);
+#pragma unroll
+    for (int k = 0; k < ONEPASS_ROWS; ++k) row[k] = nrow[k];
+    cur = nxt;
+  }
+  flush(true);  // (whatever lies beyond a ring's two lines was written straight to its place)
+}
+
 // One ticket = one partition: all its rows folded into a fresh LDS table, the table flushed into
 // the global one.  A partition holds (groups / partitions) distinct keys, chosen by the host to fit.
 __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(const PartArgs A) {
@@ -521,8 +677,14 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
         nkey[j] = 0;
         nval[j] = 0;
         if (r < end) {
-          nkey[j] = __builtin_nontemporal_load(&A.keys[r]);
-          if (A.n_inputs > 0) nval[j] = __builtin_nontemporal_load(&A.vals[r]);
+          if (A.interleaved) {
+            const KeyVal *kv = (const KeyVal *)A.keys + r;
+            nkey[j] = __builtin_nontemporal_load(&kv->key);
+            nval[j] = __builtin_nontemporal_load(&kv->val);
+          } else {
+            nkey[j] = __builtin_nontemporal_load(&A.keys[r]);
+            if (A.n_inputs > 0) nval[j] = __builtin_nontemporal_load(&A.vals[r]);
+          }
         }
       }
     };
@@ -1529,7 +1691,11 @@ hipError_t launch_spill_count(const AggSpill &sp, int n_segments, int bits, int 
 }
 
 // How the partitioning is split into passes: bits of the first level (the second takes the rest; 0 = one pass).
-int spill_level1_bits(int bits) { return bits <= 6 ? bits : bits - bits / 2; }
+int spill_level1_bits(int bits) {
+  static int levels = tuned("QE_SPILL_LEVELS", 2);  // 1: one scatter pass whatever the number of partitions (an experiment)
+  if (levels == 1) return bits;
+  return bits <= 6 ? bits : bits - bits / 2;
+}
 
 hipError_t launch_spill_cells_level1(const int32_t *cells, int32_t *cells1, int bits, int blocks, hipStream_t stream) {
   const int bits1 = spill_level1_bits(bits);
@@ -1578,6 +1744,32 @@ hipError_t launch_spill_scatter(const AggSpill &sp, int n_segments, int level, i
     attr_set = true;
   }
   hipLaunchKernelGGL(qe_spill_scatter_kernel, dim3(blocks), dim3(PART_THREADS), (size_t)a.stages * a.depth * row_bytes, stream, a);
+  return hipGetLastError();
+}
+
+bool spill_onepass_available(int bits, uint32_t n_inputs) {
+  static int on = tuned("QE_SPILL_ONEPASS", 1);  // 2: off (the two-level scatter of whole-KiB bursts instead)
+  return on != 2 && bits <= 9 && (1 << bits) <= ONEPASS_MAX_PARTS && n_inputs <= 1;
+}
+
+hipError_t launch_spill_scatter_onepass(const AggSpill &sp, int n_segments, int bits, int blocks, const int32_t *dst_cells, void *dst_rows, hipStream_t stream) {
+  if (!spill_onepass_available(bits, sp.n_inputs)) return hipErrorInvalidValue;
+  OnePassArgs a{};
+  a.sp = sp;
+  a.n_segments = n_segments;
+  a.bits = bits;
+  a.dst_cells = dst_cells;
+  a.dst = (KeyVal *)dst_rows;
+  a.n_inputs = sp.n_inputs;
+  const size_t P = (size_t)1 << bits;
+  const size_t lds = P * ONEPASS_RING * sizeof(KeyVal) + P * (3 * sizeof(uint32_t) + sizeof(unsigned long long)) + 2 * P * sizeof(uint32_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)qe_spill_scatter_onepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(qe_spill_scatter_onepass_kernel, dim3(blocks), dim3(PART_THREADS), lds, stream, a);
   return hipGetLastError();
 }
 

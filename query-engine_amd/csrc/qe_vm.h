@@ -278,7 +278,7 @@ struct PartArgs {
   uint32_t lds_limit;
   unsigned long long *ticket;      // zeroed before the launch
   int32_t ablate;                  // timing experiments only (QE_PART_ABLATE): 1 no flush, 2 no fold, 4 no lookup
-  int32_t ablate_pad;
+  int32_t interleaved;             // 1: `keys` holds (key, value) pairs of 16 bytes, one value column (the one-pass scatter's output)
 };
 
 constexpr int FIX_FRACTION_BITS = 96;  // fixed-point digits below 2^S
