@@ -1281,16 +1281,10 @@ __device__ __forceinline__ uint32_t utf8_gather_dword(const int32_t *sd, const i
   return word;
 }
 
-// Column blockIdx.y of the launch.  (src_total, the bytes of the source column: a 16-byte fetch must end inside them.)
+// Every column of the launch, chunk by chunk.  (src_total, the bytes of the source column: a 16-byte fetch must end inside them.)
 __global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel(const Utf8GatherCols C, const int32_t *idx, int64_t m_bound,
                                                                                  const unsigned long long *m_dev) {
   const int64_t m = m_dev ? (int64_t)__hip_atomic_load(m_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : m_bound;
-  const Utf8GatherCol &col = C.col[blockIdx.y];
-  const int32_t *const src_offsets = col.src_offsets;
-  const uint8_t *__restrict__ const src_bytes = col.src_bytes;
-  const int64_t src_total = col.src_total;
-  const int32_t *const dst_offsets = col.out_offsets;
-  uint8_t *__restrict__ const dst_bytes = col.out_bytes;
   __shared__ int32_t s_dst[GATHER_WAVES][65];
   __shared__ int32_t s_src[GATHER_WAVES][64];
   __shared__ __attribute__((aligned(16))) uint8_t s_stage[GATHER_WAVES][64 * GATHER_SHORT + 16];
@@ -1299,44 +1293,76 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel
   for (int64_t chunk = (int64_t)blockIdx.x * GATHER_WAVES + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * GATHER_WAVES) {
     const int64_t i = chunk * 64 + lane;
     const int rows = (int)(m - chunk * 64 < 64 ? m - chunk * 64 : 64);
+    // the chunk's row ids once for all columns; a column's offsets are fetched while the column before it is copied
+    const int64_t r = i < m ? (int64_t)idx[i] : 0;
+    int32_t n_two[2] = {0, 0}, n_dst = 0, n_end = 0;
+    auto fetch_offsets = [&](int c) {
+      if (c < C.n && i < m) {
+        __builtin_memcpy(n_two, C.col[c].src_offsets + r, 8);
+        n_dst = C.col[c].out_offsets[i];
+      }
+      if (c < C.n && lane == 0) n_end = C.col[c].out_offsets[chunk * 64 + rows];
+    };
+    fetch_offsets(0);
+    for (int c = 0; c < C.n; ++c) {
+    const Utf8GatherCol &col = C.col[c];
+    const uint8_t *__restrict__ const src_bytes = col.src_bytes;
+    const int64_t src_total = col.src_total;
+    uint8_t *__restrict__ const dst_bytes = col.out_bytes;
     int32_t my_src = 0, my_dst = 0, my_len = 0;
     if (i < m) {
-      const int64_t r = idx[i];
-      int32_t two[2];
-      __builtin_memcpy(two, src_offsets + r, 8);
-      my_src = two[0];
-      my_len = two[1] - two[0];
-      my_dst = dst_offsets[i];
+      my_src = n_two[0];
+      my_len = n_two[1] - n_two[0];
+      my_dst = n_dst;
       s_src[wave][lane] = my_src;
       s_dst[wave][lane] = my_dst;
     }
-    if (lane == 0) s_dst[wave][rows] = dst_offsets[chunk * 64 + rows];
+    if (lane == 0) s_dst[wave][rows] = n_end;
+    fetch_offsets(c + 1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's own LDS writes, before its reads below
     __builtin_amdgcn_wave_barrier();
     const int32_t *sd = s_dst[wave], *ss = s_src[wave];
     const int32_t d0 = sd[0], d1 = sd[rows];
     const int32_t a0 = d0 & ~3;  // the run's first dword
-    const bool fits = my_len <= GATHER_SHORT && (int64_t)my_src + ((my_len + 15) & ~15) <= src_total;
-    if (__ballot(!fits) == 0) {
-      // ---- short rows: a few fetches a row, the run assembled in LDS
-      const int pieces = 1 + (__ballot(my_len > 16) != 0) + (__ballot(my_len > 32) != 0) + (__ballot(my_len > 48) != 0);
+    const bool in_bounds = (int64_t)my_src + ((my_len + 15) & ~15) <= src_total;  // (a 16-byte fetch of the row's last piece ends inside the source)
+    const bool is_short = my_len <= GATHER_SHORT && in_bounds;
+    // rows a lane cannot copy by itself: longer than 64 bytes (or at the very end of the source)
+    const uint64_t long_rows = __ballot(i < m && !is_short);
+    if (long_rows == 0 || d1 - a0 <= (int32_t)(64 * GATHER_SHORT)) {
+      // ---- the run assembled in LDS: a lane fetches its own short row in pieces of 16 bytes; a row too long for that is
+      // fetched by the whole wave, a lane to a piece, the rare one (a chunk with one such row used to send all its 64 rows
+      // down the search path below: a column with 2 % long rows did so for 70 % of its chunks)
+      const uint32_t short_len = is_short ? (uint32_t)my_len : 0u;
+      const int pieces = (__ballot(short_len > 0) != 0) + (__ballot(short_len > 16) != 0) + (__ballot(short_len > 32) != 0) + (__ballot(short_len > 48) != 0);
+      auto stage_piece = [&](const uint8_t *from, uint8_t *at, int32_t here) {  // `here` (1..16) bytes of a 16-byte fetch
+        uint32_t w[4];
+        __builtin_memcpy(w, from, 16);  // (any alignment: one 16-byte load)
+        // whole dwords as (unaligned) dword writes, the up to three bytes after them one by one: seven LDS
+        // instructions a piece at most, not sixteen
+        const int32_t full = here >> 2, tail = here & 3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < full) __builtin_memcpy(at + 4 * q, &w[q], 4);
+        if (tail) {
+          const uint32_t tw = full == 0 ? w[0] : full == 1 ? w[1] : full == 2 ? w[2] : w[3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            if (t < tail) at[4 * full + t] = (uint8_t)(tw >> (8 * t));
+        }
+      };
       for (int piece = 0; piece < pieces; ++piece) {
-        const int32_t left = my_len - 16 * piece;
-        if (i < m && left > 0) {
-          uint32_t w[4];
-          __builtin_memcpy(w, src_bytes + my_src + 16 * piece, 16);  // (any alignment: one 16-byte load)
-          uint8_t *at = s_stage[wave] + (my_dst - a0) + 16 * piece;
-          // whole dwords as (unaligned) dword writes, the up to three bytes after them one by one: seven LDS
-          // instructions a piece at most, not sixteen
-          const int32_t here = left < 16 ? left : 16, full = here >> 2, tail = here & 3;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (q < full) __builtin_memcpy(at + 4 * q, &w[q], 4);
-          if (tail) {
-            const uint32_t tw = full == 0 ? w[0] : full == 1 ? w[1] : full == 2 ? w[2] : w[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-              if (t < tail) at[4 * full + t] = (uint8_t)(tw >> (8 * t));
+        const int32_t left = (int32_t)short_len - 16 * piece;
+        if (left > 0) stage_piece(src_bytes + my_src + 16 * piece, s_stage[wave] + (my_dst - a0) + 16 * piece, left < 16 ? left : 16);
+      }
+      for (uint64_t rest = long_rows; rest != 0; rest &= rest - 1) {
+        const int q = __builtin_ctzll(rest);
+        const int32_t q_src = __builtin_amdgcn_readlane(my_src, q), q_dst = __builtin_amdgcn_readlane(my_dst, q), q_len = __builtin_amdgcn_readlane(my_len, q);
+        for (int32_t off = 16 * (int32_t)lane; off < q_len; off += 16 * 64) {
+          const int32_t left = q_len - off;
+          if ((int64_t)q_src + off + 16 <= src_total) {
+            stage_piece(src_bytes + q_src + off, s_stage[wave] + (q_dst - a0) + off, left < 16 ? left : 16);
+          } else {  // the source's last bytes: one at a time
+            for (int32_t b = 0; b < left && b < 16; ++b) s_stage[wave][(q_dst - a0) + off + b] = src_bytes[q_src + off + b];
           }
         }
       }
@@ -1353,8 +1379,8 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel
         }
       }
     } else {
-      // ---- a lane takes four consecutive output bytes (one aligned dword store; the run's ragged ends go out byte by
-      // byte: the bytes next to them belong to other waves)
+      // ---- a run too long for the staging row: a lane takes four consecutive output bytes (one aligned dword store; the
+      // run's ragged ends go out byte by byte: the bytes next to them belong to other waves) and finds each byte's row
       for (int32_t p4 = a0 + 4 * (int32_t)lane; p4 < d1; p4 += 256) {
         const uint32_t word = utf8_gather_dword(sd, ss, rows, d0, d1, p4, src_bytes);
         if (p4 >= d0 && p4 + 4 <= d1) {
@@ -1366,7 +1392,8 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();  // the next chunk overwrites the offsets and the staging row
+    __builtin_amdgcn_wave_barrier();  // the next column (or chunk) overwrites the offsets and the staging row
+    }
   }
 }
 
@@ -1863,7 +1890,7 @@ hipError_t launch_exclusive_scan_i32(int32_t *data, int64_t n, int32_t *block_su
 hipError_t launch_utf8_gather_bytes(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, const unsigned long long *m_dev, hipStream_t stream) {
   if (m <= 0 || cols.n <= 0) return hipSuccess;
   if (cols.n > UTF8_GATHER_MAX_COLS) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(qe_utf8_gather_bytes_kernel, dim3(grid_for(m, 256, 8192), cols.n), dim3(GATHER_WAVES * 64), 0, stream, cols, idx, m, m_dev);
+  hipLaunchKernelGGL(qe_utf8_gather_bytes_kernel, dim3(grid_for(m, 256, 8192)), dim3(GATHER_WAVES * 64), 0, stream, cols, idx, m, m_dev);
   return hipGetLastError();
 }
 
