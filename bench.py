@@ -228,11 +228,15 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
+        import datetime
+        # (a rendezvous or a collective that never completes raises after this long instead of sitting there until somebody
+        # kills the job: QE_BENCH_TIMEOUT seconds, default 480)
+        limit = datetime.timedelta(seconds=float(os.environ.get("QE_BENCH_TIMEOUT", "480")))
         with StdoutToStderr():
             if backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
             else:
-                dist.init_process_group("gloo")
+                dist.init_process_group("gloo", timeout=limit)
             dist.barrier()  # brings torch's communicator up here, inside the redirection
     else:
         torch.cuda.set_device(0)

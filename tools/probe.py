@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Small single-GPU driver for profiling one configuration under rocprofv3.
 
-usage: probe.py <c2|c3|c5|c4|c5m|p> [rows] [reps]   (c5m: the c5 plan over 1 M uniform keys)
+usage: probe.py <c2|c3|c5|c4|c5m|p|utf8> [rows] [reps]   (c5m: the c5 plan over 1 M uniform keys; utf8: the reference's
+test_filter shape at 100 M rows, bench.py's utf8_filter_config, with the deferred row count)
 """
 import importlib
 import os
@@ -22,6 +23,13 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     ctx = qe.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    if cfg == "utf8":
+        import json
+        import bench
+        ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | qe.FLAG_JIT_SYNC | qe.FLAG_DEFERRED_ROW_COUNT)
+        r = bench.utf8_filter_config(qe, ctx, torch, dev)
+        print("utf8 rows", r["rows"], "ms", r["ms_per_step"], "bytes_per_row", r["bytes_per_row"], "frac", r["frac_hbm_peak_end_to_end"], json.dumps(r["kernels_ms_per_step"]))
+        return
     k = torch.empty(n, dtype=torch.int64, device=dev)
     a = torch.empty(n, dtype=torch.float64, device=dev)
     b = torch.empty(n, dtype=torch.float64, device=dev)
