@@ -35,15 +35,16 @@ struct Context : std::enable_shared_from_this<Context> {
   void *filter_scratch = nullptr;
   size_t filter_scratch_cap = 0;
   unsigned long long *counters = nullptr;  // small device scratch for counts
-  // Two pinned buffers for bulk host -> device copies (file scans), used in turn: the host fills one
-  // while the copy out of the other is still in flight.  They outlive the files that use them.
+  // A ring of pinned buffers for bulk host -> device copies (file scans), used in turn: reader threads fill
+  // the next ones while the copies out of the earlier ones are still in flight.  They outlive the files that use them.
   struct Staging {
     void *ptr = nullptr;
     size_t cap = 0;
     hipEvent_t copied = nullptr;  // recorded after the copy out of the buffer
     bool pending = false;
   };
-  Staging staging[2];
+  static constexpr int STAGING_BUFFERS = 6;
+  Staging staging[STAGING_BUFFERS];
   int next_staging = 0;
   // Plain host memory that scans reuse for compressed bytes (a fresh allocation per column chunk
   // costs a page fault per 4 KiB on its first touch).

@@ -34,11 +34,12 @@ struct ScanIter : Iter {
   std::vector<int> parquet_columns;
   size_t first = 0, end = 0;  // row groups of the file this scan covers
   size_t cur = 0;
+  ParquetReadAhead ahead;     // the next chunks' bytes, already on their way into pinned memory
   bool next(Batch &out) override {
     if (parquet) {
       // ScanIterator::next (physical_plan/mod.rs:99-109) over the file reader's row groups
       if (first + cur >= end) return false;
-      out = parquet_read_row_group(ctx, *parquet, (int)(first + cur++), parquet_columns);
+      out = parquet_read_row_group(ctx, *parquet, (int)(first + cur++), parquet_columns, &ahead, (int)end);
       return true;
     }
     if (cur >= batches.size()) return false;

@@ -14,7 +14,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cerrno>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
@@ -421,7 +423,7 @@ void parallel_for(size_t n, F fn) {
 // The staging buffer to fill next, at least `bytes` large; waits until the copy that last read it is done.
 Context::Staging &take_staging(Context *ctx, size_t bytes) {
   Context::Staging &s = ctx->staging[ctx->next_staging];
-  ctx->next_staging ^= 1;
+  ctx->next_staging = (ctx->next_staging + 1) % Context::STAGING_BUFFERS;
   ctx->bind();
   if (s.pending) {
     QE_HIP(hipEventSynchronize(s.copied));
@@ -459,7 +461,23 @@ struct PageRec {
   size_t body;  // offset of the page body in the raw chunk
 };
 
-Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, const ParquetChunkMeta &cm, int64_t n_rows) {
+// QE_PARQUET_TRACE=1: where the host's time goes, per column chunk, on stderr (waiting for a staging buffer, reading the
+// file, walking the pages, queueing the copy and the decode kernels).
+static bool parquet_trace() {
+  static const bool on = getenv("QE_PARQUET_TRACE") != nullptr;
+  return on;
+}
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Pinned bytes a chunk that is stored uncompressed needs: the chunk as it lies in the file, then room for the descriptor tables.
+static size_t plain_chunk_staging_bytes(const ParquetChunkMeta &cm) {
+  const size_t raw_len = (size_t)cm.size;
+  return align16(raw_len + 16) + ((size_t)1 << 16) + raw_len / 8;
+}
+
+Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, const ParquetChunkMeta &cm, int64_t n_rows, ParquetReadAhead::Read *ahead = nullptr) {
+  const double t_start = parquet_trace() ? now_ms() : 0.0;
+  double t_staged = 0.0, t_read = 0.0, t_walked = 0.0;
   if (!col.type)
     fail(QE_ERR_PHYSICAL_TYPE_NOT_SUPPORTED, "Physical type `" + col.type_text + "` is not supported (parquet column `" + col.name + "`).");
   if (cm.start < 4 || cm.size < 0 || cm.start + cm.size > f.file_size) bad_file("column chunk outside the file");
@@ -473,15 +491,26 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
   const size_t table_room = ((size_t)1 << 16) + raw_len / 8;
   uint8_t *raw;
   Context::Staging *stage = nullptr;
-  if (cm.codec == CODEC_NONE) {
-    // the image is the chunk as it lies in the file: read it straight into pinned memory
-    stage = &take_staging(ctx, align16(raw_len + 16) + table_room);
+  (void)table_room;
+  if (ahead && ahead->stage) {
+    // read ahead of time into a staging buffer of its own: wait for the reader (its failure is thrown here)
+    stage = ahead->stage;
     raw = (uint8_t *)stage->ptr;
+    if (parquet_trace()) t_staged = now_ms();
+    ahead->done.get();
   } else {
-    if (ctx->host_scratch.size() < raw_len + 16) ctx->host_scratch.resize(raw_len + raw_len / 4 + 16);
-    raw = ctx->host_scratch.data();
+    if (cm.codec == CODEC_NONE) {
+      // the image is the chunk as it lies in the file: read it straight into pinned memory
+      stage = &take_staging(ctx, plain_chunk_staging_bytes(cm));
+      raw = (uint8_t *)stage->ptr;
+    } else {
+      if (ctx->host_scratch.size() < raw_len + 16) ctx->host_scratch.resize(raw_len + raw_len / 4 + 16);
+      raw = ctx->host_scratch.data();
+    }
+    if (parquet_trace()) t_staged = now_ms();
+    read_parallel(f, cm.start, raw, raw_len);
   }
-  read_parallel(f, cm.start, raw, raw_len);
+  if (parquet_trace()) t_read = now_ms();
   std::vector<PageRec> recs;
   size_t image_need = 0;
   {
@@ -641,12 +670,17 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
   at = align16(at + walks.size() * sizeof(PqWalk));
   const size_t total = at + 16;
   if (total > stage->cap) {
-    // tables did not fit behind the image: move to a larger pinned buffer
-    std::vector<uint8_t> keep(image, image + image_len);
-    ctx->next_staging = (int)(stage - ctx->staging);
-    stage = &take_staging(ctx, total);
-    image = (uint8_t *)stage->ptr;
-    memcpy(image, keep.data(), image_len);
+    // tables did not fit behind the image: this staging buffer grows (nobody else holds it: its last copy was waited
+    // for when it was handed out)
+    void *bigger = nullptr;
+    const size_t cap = total + total / 4;
+    ctx->bind();
+    QE_HIP(hipHostMalloc(&bigger, cap, hipHostMallocDefault));
+    memcpy(bigger, image, image_len);
+    QE_HIP(hipHostFree(stage->ptr));
+    stage->ptr = bigger;
+    stage->cap = cap;
+    image = (uint8_t *)bigger;
   }
   uint8_t *st = (uint8_t *)stage->ptr;
   memset(st + image_len, 0, pages_at - image_len);
@@ -655,6 +689,7 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
   if (!level_runs.empty()) memcpy(st + level_runs_at, level_runs.data(), level_runs.size() * sizeof(PqRun));
   if (!walks.empty()) memcpy(st + walks_at, walks.data(), walks.size() * sizeof(PqWalk));
 
+  if (parquet_trace()) t_walked = now_ms();
   ctx->bind();
   BufferPtr dev = device_buffer(ctx, total);
   QE_HIP(hipMemcpyAsync(dev->ptr, st, total, hipMemcpyHostToDevice, ctx->stream));
@@ -755,6 +790,11 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
   }
   // Temporaries go back to the pool here while the stream may still use them: the pool only hands
   // blocks to work queued later on the same stream.
+  if (parquet_trace()) {
+    const double t_end = now_ms();
+    fprintf(stderr, "qe_gpu parquet: column %s, %.1f MB: staging buffer %.3f ms, read %.3f ms (%.1f GB/s), pages %.3f ms, queueing %.3f ms\n", col.name.c_str(),
+            (double)raw_len / 1e6, t_staged - t_start, t_read - t_staged, (double)raw_len / 1e6 / std::max(t_read - t_staged, 1e-6), t_walked - t_read, t_end - t_walked);
+  }
   return out;
 }
 
@@ -876,7 +916,31 @@ std::vector<int> parquet_project(const ParquetFile &file, const std::vector<std:
   return out;
 }
 
-Batch parquet_read_row_group(Context *ctx, ParquetFile &file, int row_group, const std::vector<int> &columns) {
+// Chunks in flight ahead of the one being decoded, the current one included.  Each holds a staging buffer of the ring;
+// the ring has as many again, so that the buffer a new read takes is one whose copy to the device was queued three
+// chunks ago and has long finished - the host never waits for it.
+constexpr int READ_AHEAD_DEPTH = Context::STAGING_BUFFERS / 2;
+
+// Starts reading chunk (row_group, column) into the next staging buffer on a thread of its own - for chunks that are
+// stored uncompressed (the file's bytes are the image the device decodes); others are read when their turn comes.
+static void read_ahead_issue(Context *ctx, ParquetFile &file, ParquetReadAhead &ahead, int row_group, int column) {
+  ParquetReadAhead::Read r;
+  r.row_group = row_group;
+  r.column = column;
+  const ParquetChunkMeta &cm = file.row_groups[(size_t)row_group].chunks[(size_t)column];
+  const bool plain = cm.codec == CODEC_NONE && file.columns[(size_t)column].type != 0 && cm.start >= 4 && cm.size >= 0 && cm.start + cm.size <= file.file_size;
+  if (plain) {
+    r.stage = &take_staging(ctx, plain_chunk_staging_bytes(cm));
+    uint8_t *dst = (uint8_t *)r.stage->ptr;
+    ParquetFile *f = &file;
+    const int64_t start = cm.start;
+    const size_t len = (size_t)cm.size;
+    r.done = std::async(std::launch::async, [f, start, dst, len] { read_parallel(*f, start, dst, len); });
+  }
+  ahead.queue.push_back(std::move(r));
+}
+
+Batch parquet_read_row_group(Context *ctx, ParquetFile &file, int row_group, const std::vector<int> &columns, ParquetReadAhead *ahead, int last_row_group) {
   if (row_group < 0 || row_group >= (int)file.row_groups.size()) fail(QE_ERR_EXCEEDING_BOUNDS, "row group index out of range");
   const ParquetRowGroup &rg = file.row_groups[row_group];
   Batch b;
@@ -889,12 +953,41 @@ Batch parquet_read_row_group(Context *ctx, ParquetFile &file, int row_group, con
   }
   unsigned long long *err = ctx->counters + 32;
   QE_HIP(hipMemsetAsync(err, 0, 2 * sizeof(unsigned long long), ctx->stream));
-  for (int c : columns) {
+  for (int c : columns)
     if (c < 0 || c >= (int)file.columns.size()) fail(QE_ERR_EXCEEDING_BOUNDS, "column index out of range");
-    b.cols.push_back(decode_chunk(ctx, file, file.columns[c], rg.chunks[c], rg.num_rows));
+  if (last_row_group < 0 || last_row_group > (int)file.row_groups.size()) last_row_group = (int)file.row_groups.size();
+  // the scan order from a chunk on: the rest of this row group, then the next row groups' columns
+  auto next_of = [&](int &g, size_t &ci) {
+    if (++ci >= columns.size()) {
+      ci = 0;
+      ++g;
+    }
+    return g < last_row_group && !columns.empty();
+  };
+  for (size_t ci = 0; ci < columns.size(); ++ci) {
+    const int c = columns[ci];
+    ParquetReadAhead::Read mine;
+    if (ahead) {
+      // reads left over from a scan that went another way (a restart) are waited for and dropped
+      while (!ahead->queue.empty() && (ahead->queue.front().row_group != row_group || ahead->queue.front().column != c)) {
+        if (ahead->queue.front().done.valid()) ahead->queue.front().done.wait();
+        ahead->queue.pop_front();
+      }
+      if (ahead->queue.empty()) read_ahead_issue(ctx, file, *ahead, row_group, c);
+      // top up: the chunks after the last one queued
+      int g = ahead->queue.back().row_group;
+      size_t at = 0;
+      while (at < columns.size() && columns[at] != ahead->queue.back().column) ++at;
+      while ((int)ahead->queue.size() < READ_AHEAD_DEPTH && at < columns.size() && next_of(g, at)) read_ahead_issue(ctx, file, *ahead, g, columns[at]);
+      mine = std::move(ahead->queue.front());
+      ahead->queue.pop_front();
+    }
+    b.cols.push_back(decode_chunk(ctx, file, file.columns[c], rg.chunks[c], rg.num_rows, mine.stage ? &mine : nullptr));
   }
   QE_HIP(hipMemcpyAsync(ctx->host_counters + 9, err, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  const double t_sync = parquet_trace() ? now_ms() : 0.0;
   ctx->sync();
+  if (parquet_trace()) fprintf(stderr, "qe_gpu parquet: row group %d: waited %.3f ms for the device\n", row_group, now_ms() - t_sync);
   if (ctx->host_counters[9]) bad_file("row group " + std::to_string(row_group) + ": page contents contradict their headers");
   return b;
 }

@@ -2,6 +2,8 @@
 // the GPU.  The host reads the footer and the page headers; column chunks are shipped to HBM as
 // they are in the file (after block decompression, where the file uses it) and decoded there.
 #pragma once
+#include <deque>
+#include <future>
 #include <memory>
 #include <string>
 #include <vector>
@@ -48,8 +50,22 @@ std::shared_ptr<ParquetFile> parquet_open(const std::string &path);
 // file order (data_source.rs:49-62).
 std::vector<int> parquet_project(const ParquetFile &file, const std::vector<std::string> &projection);
 
+// Column chunks on their way from the file into pinned staging buffers, read ahead of the chunk that is being decoded
+// (by reader threads of their own): while the device copies and decodes one chunk - and while the host waits for a row
+// group's last one - the next chunks, the next row group's included, are already being read.  Owned by the scan.
+struct ParquetReadAhead {
+  struct Read {
+    int row_group = -1, column = -1;
+    Context::Staging *stage = nullptr;
+    std::future<void> done;
+  };
+  std::deque<Read> queue;  // in scan order
+};
+
 // One row group, the given columns, decoded into a device-resident batch (the reference's
-// FileReader yields one chunk per row group).
-Batch parquet_read_row_group(Context *ctx, ParquetFile &file, int row_group, const std::vector<int> &columns);
+// FileReader yields one chunk per row group).  `ahead` (may be null) carries reads over to the scan's
+// next call; `last_row_group` bounds what is read ahead (exclusive).
+Batch parquet_read_row_group(Context *ctx, ParquetFile &file, int row_group, const std::vector<int> &columns, ParquetReadAhead *ahead = nullptr,
+                             int last_row_group = -1);
 
 }  // namespace qe
