@@ -1391,6 +1391,7 @@ struct SpillState {
   uint64_t capacity;
   uint64_t base;     // first row of this wave's region
   uint32_t cursor;   // rows logged so far (wave-uniform)
+  uint32_t pairs;    // AggSpill::pairs
 };
 
 __device__ __forceinline__ SpillState spill_begin(const AggSpill &sp, uint32_t wave_in_block) {
@@ -1400,6 +1401,7 @@ __device__ __forceinline__ SpillState spill_begin(const AggSpill &sp, uint32_t w
   s.capacity = sp.capacity;
   s.base = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block) * sp.rows_per_wave;
   s.cursor = 0;
+  s.pairs = sp.pairs;
   return s;
 }
 __device__ __forceinline__ void spill_end(const AggSpill &sp, const SpillState &s, uint32_t wave_in_block, uint32_t lane) {
@@ -1408,11 +1410,12 @@ __device__ __forceinline__ void spill_end(const AggSpill &sp, const SpillState &
 
 // Logs one evaluated accumulator input of the spilled rows to value column `col`.
 __device__ __forceinline__ void spill_values(const SpillState &sp, uint32_t col, const Slot &in, const AggRows &G) {
-  unsigned long long *dst = sp.vals + (uint64_t)col * sp.capacity + G.spill_pos;
+  // (a log of pairs has one value column: the value sits behind its key)
+  unsigned long long *dst = sp.pairs ? sp.keys + 2 * G.spill_pos + 1 : sp.vals + (uint64_t)col * sp.capacity + G.spill_pos;
   uint32_t k = 0;
 #pragma unroll
   for (int j = 0; j < VM_R; ++j) {
-    if ((G.spill_mb >> j) & 1u) dst[k] = in.v[j];
+    if ((G.spill_mb >> j) & 1u) dst[k << sp.pairs] = in.v[j];
     k += (G.spill_mb >> j) & 1u;
   }
 }
@@ -1494,7 +1497,7 @@ __device__ __forceinline__ void agg_lookup(const LdsTable &L, const AggTable &T,
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) {
         if ((miss >> j) & 1u) {
-          sp.keys[G.spill_pos + k] = G.key[j];
+          sp.keys[(G.spill_pos + k) << sp.pairs] = G.key[j];
           G.slot[j] = SLOT_NONE;
         }
         k += (miss >> j) & 1u;

@@ -1031,11 +1031,23 @@ static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &b
   const int64_t nsteps = (args.n_rows + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
   const int64_t steps_per_wave = (nsteps + sp.waves - 1) / sp.waves;
   AggSpill &a = args.spill;
-  a.rows_per_wave = (uint32_t)(steps_per_wave * VM_WAVE_ROWS);
+  // A region's stride is an odd number of 256-byte pieces: the waves fill their regions at about one pace, and with a
+  // stride that is a multiple of a few KiB (whole steps of 256 rows: 512 KiB at 2^28 rows) they would all be writing
+  // to the same few memory channels at any one time.
+  static const int region_pad = [] {
+    const char *e = getenv("QE_SPILL_REGION_PAD");
+    return e ? atoi(e) : 0;
+  }();
+  a.rows_per_wave = (uint32_t)(steps_per_wave * VM_WAVE_ROWS + region_pad);
   a.capacity = (uint64_t)sp.waves * a.rows_per_wave;
   a.n_inputs = (uint32_t)inputs.size();
-  sp.keys = device_buffer(ctx, a.capacity * 8 + 64);
-  sp.vals = device_buffer(ctx, a.capacity * 8 * a.n_inputs + 64);
+  static const bool pairs_on = [] {
+    const char *e = getenv("QE_SPILL_PAIRS");  // 0: a key column and a value column whatever the number of value columns
+    return e ? atoi(e) != 0 : true;
+  }();
+  a.pairs = pairs_on && a.n_inputs == 1 ? 1u : 0u;
+  sp.keys = device_buffer(ctx, a.capacity * (a.pairs ? 16 : 8) + 64);
+  sp.vals = device_buffer(ctx, a.pairs ? 64 : a.capacity * 8 * a.n_inputs + 64);
   sp.counts = device_buffer(ctx, (size_t)sp.waves * 4 + 64);
   QE_HIP(hipMemsetAsync(sp.counts->ptr, 0, (size_t)sp.waves * 4, ctx->stream));
   a.keys = (unsigned long long *)sp.keys->ptr;

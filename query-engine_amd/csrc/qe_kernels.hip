@@ -238,6 +238,18 @@ constexpr int SCATTER_MAX_STAGES = 512;
 constexpr int SCATTER_ROWS = 4;       // rows per thread and round
 constexpr int SCATTER_MAX_INPUTS = 8;  // = SPILL_MAX_INPUTS of the host
 
+// A logged row with one value column, and its streaming load as one 16-byte access (two 8-byte loads of the halves
+// each touch every line of a wave's stretch).
+struct alignas(16) KeyVal { unsigned long long key, val; };
+typedef unsigned long long qe_ull2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ KeyVal load_pair_streaming(const KeyVal *p) {
+  const qe_ull2 v = __builtin_nontemporal_load((const qe_ull2 *)p);
+  KeyVal r;
+  r.key = v.x;
+  r.val = v.y;
+  return r;
+}
+
 // Partition of a key: the top bits of the 32-bit hash whose low bits pick the slot in the LDS tables (three 32-bit
 // multiplies; a 64-bit mixer costs several times that, per row and pass).
 __device__ __forceinline__ uint32_t partition_of(unsigned long long key, int bits) { return hash32(key) >> (32 - bits); }
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_count_kernel(AggSpill s
   for (int seg = seg0; seg < seg_end; seg += seg_step) {
     const uint32_t cnt = sp.counts[seg];
     const uint64_t base = (uint64_t)seg * sp.rows_per_wave;
-    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) atomicAdd(&s_cell[partition_of(sp.keys[base + i], bits)], 1u);
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) atomicAdd(&s_cell[partition_of(sp.keys[(base + i) << sp.pairs], bits)], 1u);
     if (threadIdx.x == 0) mine += cnt;
   }
   __syncthreads();
@@ -397,8 +409,14 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_kernel(const Sc
       key[k] = 0;
       val0[k] = 0;
       if (r.valid && i < r.cnt) {
-        key[k] = __builtin_nontemporal_load(&src_keys[r.first + i]);
-        if (n_in > 0) val0[k] = __builtin_nontemporal_load(&src_vals[r.first + i]);
+        if (A.level == 1 && A.sp.pairs) {  // (key, value) pairs
+          const KeyVal kv = load_pair_streaming((const KeyVal *)src_keys + (r.first + i));
+          key[k] = kv.key;
+          val0[k] = kv.val;
+        } else {
+          key[k] = __builtin_nontemporal_load(&src_keys[r.first + i]);
+          if (n_in > 0) val0[k] = __builtin_nontemporal_load(&src_vals[r.first + i]);
+        }
       }
     }
   };
@@ -489,7 +507,6 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_kernel(const Sc
 // bursts needed two.  A row's place in its partition is fixed when it arrives (a counter per partition), so a row that
 // finds its ring full is written straight to its place instead (a partial line, rare: rows arrive at half the rings'
 // capacity per round) and the line it belongs to is completed around it.  Only a cell's first and last line are partial.
-struct alignas(16) KeyVal { unsigned long long key, val; };
 constexpr int ONEPASS_RING = 16;      // rows a partition's ring holds (two lines of eight)
 constexpr int ONEPASS_ROWS = 2;       // rows per thread and round
 constexpr int ONEPASS_MAX_PARTS = 512;
@@ -595,8 +612,12 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_onepass_kernel(
       row[k].key = 0;
       row[k].val = 0;
       if (r.valid && i < r.cnt) {
-        row[k].key = __builtin_nontemporal_load(&A.sp.keys[r.first + i]);
-        if (A.n_inputs > 0) row[k].val = __builtin_nontemporal_load(&A.sp.vals[r.first + i]);
+        if (A.sp.pairs) {
+          row[k] = load_pair_streaming((const KeyVal *)A.sp.keys + (r.first + i));
+        } else {
+          row[k].key = __builtin_nontemporal_load(&A.sp.keys[r.first + i]);
+          if (A.n_inputs > 0) row[k].val = __builtin_nontemporal_load(&A.sp.vals[r.first + i]);
+        }
       }
     }
   };
@@ -651,6 +672,7 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
   none.capacity = 0;
   none.base = 0;
   none.cursor = 0;
+  none.pairs = 0;
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -678,9 +700,9 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
         nval[j] = 0;
         if (r < end) {
           if (A.interleaved) {
-            const KeyVal *kv = (const KeyVal *)A.keys + r;
-            nkey[j] = __builtin_nontemporal_load(&kv->key);
-            nval[j] = __builtin_nontemporal_load(&kv->val);
+            const KeyVal kv = load_pair_streaming((const KeyVal *)A.keys + r);
+            nkey[j] = kv.key;
+            nval[j] = kv.val;
           } else {
             nkey[j] = __builtin_nontemporal_load(&A.keys[r]);
             if (A.n_inputs > 0) nval[j] = __builtin_nontemporal_load(&A.vals[r]);
@@ -1662,6 +1684,8 @@ hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipSt
 #ifdef QE_ABLATE  // timing experiments only (results are wrong): compiled in by a build with -DQE_ABLATE, never in the shipped library
     static int no_flush = tuned("QE_SPILL_ABLATE_FLUSH", 0);
     if (no_flush) args.tune |= 4u;
+    static int first = tuned("QE_SPILL_ABLATE_FIRST", 0);  // 16: no log stores, 32: no look at the table, 64: no partition histogram, 128: no value stores
+    args.tune |= (uint32_t)first & 0x1f0u;
 #endif
     static int prio = tuned("QE_SPILL_PRIO", 1);
     if (prio) args.tune |= 8u;  // (bit 3: the waves of a SIMD take the high priority in turn)

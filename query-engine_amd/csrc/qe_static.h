@@ -734,37 +734,53 @@ struct SpillRows {
   uint32_t slot8[VM_R];  // byte offset (slot x 8) into the key array of rows whose group is in the LDS table
   uint32_t hit;          // those rows
   uint32_t miss;         // rows logged instead
-  uint64_t pos;          // log position of the lane's first logged row; the others follow
+  uint64_t pos;          // log position of the wave-step's first logged row
+  uint32_t off[VM_R];    // + this: where the lane's row j goes
 };
 
-__device__ __forceinline__ void spill_lookup(const LdsTable &L, uint32_t active, SpillRows &G, SpillState &sp, uint32_t *hist, int hist_bits) {
+__device__ __forceinline__ void spill_lookup(const LdsTable &L, uint32_t active, SpillRows &G, SpillState &sp, uint32_t *hist, int hist_bits,
+                                             uint32_t ablate = 0) {
+#ifdef QE_ABLATE  // timing experiments (results are wrong): 32 = no look at the table, 16 = no stores into the log, 64 = no partition histogram
+  const uint32_t hit = (ablate & 32u) ? 0u : lds_two_pairs_find_or_claim4(L, G.key, active, G.slot8);
+  if (ablate & 64u) hist = nullptr;
+#else
   const uint32_t hit = lds_two_pairs_find_or_claim4(L, G.key, active, G.slot8);
+#endif
   const uint32_t miss = active & ~hit;
   G.hit = hit;
   G.miss = miss;
   G.pos = 0;
   const uint64_t any = __ballot(miss != 0);
   if (any != 0) {
-    // the rows without a slot go to the wave's log, in lane order
-    const uint32_t mine = (uint32_t)__popc(miss);
-    uint32_t before = 0, total = 0;
-#pragma unroll
-    for (int bit = 0; bit < 3; ++bit) {
-      const uint64_t m = __ballot(((mine >> bit) & 1u) != 0);
-      before += mbcnt64(m) << bit;
-      total += (uint32_t)__popcll(m) << bit;
-    }
-    G.pos = sp.base + sp.cursor + before;
-    uint32_t k = 0;
+    // The rows without a slot go to the wave's log slot by slot: the lanes' rows j lie next to each other, so each of
+    // the four store instructions writes one dense run and a cache line of the log is written by one instruction (in
+    // lane order - a lane's rows next to each other - every instruction touched every line of the step's stretch:
+    // 125 M write requests reached the L2 for 35 M lines; first pass of C4 1.34 -> 1.30 ms, a million uniform keys
+    // 2.28 -> 2.25).
+    G.pos = sp.base + sp.cursor;
+#ifdef QE_ABLATE
+    if (ablate & 0x100u) G.pos = sp.base;  // every step over the region's first rows: the stores without their traffic to memory
+#endif
+    uint32_t run = 0;
 #pragma unroll
     for (int j = 0; j < VM_R; ++j) {
-      if ((miss >> j) & 1u) {
-        sp.keys[G.pos + k] = G.key[j];  // (a streaming store here measured slower: the partial lines of a wave no longer merge)
+      const bool mine = ((miss >> j) & 1u) != 0;
+      const uint64_t m = __ballot(mine);
+      G.off[j] = run + mbcnt64(m);
+      run += (uint32_t)__popcll(m);
+#ifdef QE_ABLATE
+      if (ablate & 16u) {
+        if (mine && hist) atomicAdd(&hist[hash32(G.key[j]) >> (32 - hist_bits)], 1u);
+        continue;
+      }
+#endif
+      if (mine) {
+        // (a log of pairs: the key is stored together with its value, below)
+        if (!sp.pairs) sp.keys[G.pos + G.off[j]] = G.key[j];  // (a streaming store here measured slower: the partial lines of a wave no longer merge)
         if (hist) atomicAdd(&hist[hash32(G.key[j]) >> (32 - hist_bits)], 1u);  // (= partition_of: what the partition passes go by)
       }
-      k += (miss >> j) & 1u;
     }
-    sp.cursor += total;
+    sp.cursor += run;
   }
 }
 
@@ -842,20 +858,33 @@ __device__ __forceinline__ void spill_tasks_static(const AggArgs &A, const LdsTa
       for (int j = 0; j < VM_R; ++j) G.key[j] |= (S[0].v[j] & fmask) << sh;
     } else if constexpr (role == ROLE_LOOKUP) {
       if (__ballot(c.active != 0) == 0) return;
+#ifdef QE_ABLATE
+      spill_lookup(L, c.active, G, sp, hist, A.cell_bits, A.tune);
+#else
       spill_lookup(L, c.active, G, sp, hist, A.cell_bits);
+#endif
       if constexpr (Spec::n_accs > SPILL_ROW_MAJOR_ACCS || Spec::n_accs == 0) {
 #pragma unroll
         for (int j = 0; j < VM_R; ++j)
           if ((G.hit >> j) & 1u) atomicAdd((uint32_t *)((char *)L.rowcnt + (G.slot8[j] >> 1)), 1u);
       }
     } else {
+#ifdef QE_ABLATE
+      if (A.tune & 0x90u) {  // (128: the keys are logged, the values are not)
+      } else
+#endif
       if (G.miss != 0 && A.spill_col[idx] != 0xffu) {
-        unsigned long long *dst = sp.vals + (uint64_t)A.spill_col[idx] * sp.capacity + G.pos;
-        uint32_t k = 0;
+        if (sp.pairs) {
+          // one 16-byte store a row: half the store instructions of a key column and a value column
+          ulonglong2 *dst = (ulonglong2 *)sp.keys + G.pos;
 #pragma unroll
-        for (int j = 0; j < VM_R; ++j) {
-          if ((G.miss >> j) & 1u) dst[k] = S[0].v[j];
-          k += (G.miss >> j) & 1u;
+          for (int j = 0; j < VM_R; ++j)
+            if ((G.miss >> j) & 1u) dst[G.off[j]] = make_ulonglong2((unsigned long long)G.key[j], (unsigned long long)S[0].v[j]);
+        } else {
+          unsigned long long *dst = sp.vals + (uint64_t)A.spill_col[idx] * sp.capacity + G.pos;
+#pragma unroll
+          for (int j = 0; j < VM_R; ++j)
+            if ((G.miss >> j) & 1u) dst[G.off[j]] = S[0].v[j];
         }
       }
       if constexpr (Spec::n_accs <= SPILL_ROW_MAJOR_ACCS) {
@@ -914,6 +943,8 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_spill_static
     G.hit = 0;
     G.miss = 0;
     G.pos = 0;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) G.off[j] = 0;
     Slot in[Spec::n_accs > 0 && Spec::n_accs <= SPILL_ROW_MAJOR_ACCS ? Spec::n_accs : 1];
     spill_tasks_static<Spec, 0>(A, L, c, K, G, in, sp, hist);
   }
@@ -922,6 +953,9 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_spill_static
     // this workgroup's column of the partition passes' cell table, and its share of the log's length
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < (1u << A.cell_bits); p += blockDim.x) A.cells[(size_t)p * gridDim.x + blockIdx.x] = (int32_t)hist[p];
+#ifdef QE_ABLATE
+    if (A.tune & 0x150u) sp.cursor = 0;  // (the log is not what the histogram says: the partition passes see none)
+#endif
     if (lane == 0 && sp.cursor != 0) atomicAdd(A.cells_total, (unsigned long long)sp.cursor);
   }
   if (!(A.tune & 4u)) agg_flush(L, A.table, A.accs, Spec::n_accs);  // (bit 2: timing experiments)

@@ -222,7 +222,9 @@ struct AggSpill {
   // (workgroup b takes b, b + blocks, ...), n = runs of n (workgroup b takes [b n, (b + 1) n): the segments of first-pass
   // workgroup b, which is what lets that workgroup count its own rows per partition).
   uint32_t seg_chunk;
-  uint32_t seg_pad;
+  // 1: a log with one value column holds (key, value) pairs of 16 bytes in `keys` (row i at keys[2 i], keys[2 i + 1];
+  // `vals` is not used): the first pass writes a row with one 16-byte store, the scatter reads it with one load.
+  uint32_t pairs;
 };
 
 struct AggArgs {

@@ -64,12 +64,23 @@ def main():
         return qe.AggregateExec([proj], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None)],
                                 group_capacity_hint=1_100_000 if cfg == "c5m" else 64)
 
-    out = list(plan().execute())[0]
+    def run():
+        try:
+            return list(plan().execute())[0]
+        except qe.QeError:
+            if "QE_SPILL_ABLATE_FIRST" not in os.environ:  # (a library built for timing experiments may leave nothing to return)
+                raise
+
+            class Nothing:
+                num_rows = -1
+            return Nothing()
+
+    out = run()
     torch.cuda.synchronize()
     ctx.profile(True)
     t0 = time.perf_counter()
     for _ in range(reps):
-        out = list(plan().execute())[0]
+        out = run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     print(cfg, "rows", n, "ms", dt * 1e3, "Grows/s", n / dt / 1e9, "out_rows", out.num_rows, ctx.profile_read())
