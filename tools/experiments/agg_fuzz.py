@@ -20,7 +20,8 @@ from test_gpu_parity import C, agg_columns, run_agg
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 ctx = qe.Context(0)
-ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | (qe.FLAG_JIT_SYNC if os.environ.get("QE_FUZZ_JIT") == "1" else 0) |
+ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | (qe.FLAG_DEFERRED_ROW_COUNT if os.environ.get("QE_FUZZ_DEFER_ROWS") == "1" else 0) |
+              (qe.FLAG_JIT_SYNC if os.environ.get("QE_FUZZ_JIT") == "1" else 0) |
               (qe.FLAG_DETERMINISTIC_SUM if os.environ.get("QE_FUZZ_DET") == "1" else 0))  # QE_FUZZ_DET: order-independent sums
 r = np.random.default_rng(seed0)
 bad = 0

@@ -19,7 +19,8 @@ from util import gpu_batch
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 ctx = qe.Context(0)
-ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | (qe.FLAG_JIT_SYNC if os.environ.get("QE_FUZZ_JIT") == "1" else 0))
+ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | (qe.FLAG_DEFERRED_ROW_COUNT if os.environ.get("QE_FUZZ_DEFER_ROWS") == "1" else 0) |
+              (qe.FLAG_JIT_SYNC if os.environ.get("QE_FUZZ_JIT") == "1" else 0))
 bad = 0
 for rnd in range(4):
     cols = make_columns(700 + 311 * rnd, seed=100 + rnd + seed0)

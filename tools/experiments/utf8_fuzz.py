@@ -20,7 +20,8 @@ from util import gpu_batch
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 ctx = qe.Context(0)
-ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | (qe.FLAG_JIT_SYNC if os.environ.get("QE_FUZZ_JIT") == "1" else 0))
+ctx.set_flags(qe.FLAG_REFERENCE_SCALAR_ARRAY_SWAP | (qe.FLAG_DEFERRED_ROW_COUNT if os.environ.get("QE_FUZZ_DEFER_ROWS") == "1" else 0) |
+              (qe.FLAG_JIT_SYNC if os.environ.get("QE_FUZZ_JIT") == "1" else 0))
 r = np.random.default_rng(seed0)
 WORDS = ["", "a", "ab", "abc", "Ünïcode", "a longer string with spaces", "z" * 70, "Female", "Male", "x" * 300]
 bad = 0
