@@ -975,6 +975,31 @@ __device__ __forceinline__ uint32_t hash32(uint64_t key) {
   return h;
 }
 
+// A logged row with one value column, and its streaming load as one 16-byte access (two 8-byte loads of the halves
+// each touch every line of a wave's stretch).
+struct alignas(16) KeyVal { unsigned long long key, val; };
+typedef unsigned long long qe_ull2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ KeyVal load_pair_streaming(const KeyVal *p) {
+  const qe_ull2 v = __builtin_nontemporal_load((const qe_ull2 *)p);
+  KeyVal r;
+  r.key = v.x;
+  r.val = v.y;
+  return r;
+}
+
+// Partition of a key: the top bits of the 32-bit hash whose low bits pick the slot in the LDS tables (three 32-bit
+// multiplies; a 64-bit mixer costs several times that, per row and pass).
+__device__ __forceinline__ uint32_t partition_of(unsigned long long key, int bits) { return hash32(key) >> (32 - bits); }
+
+// Workgroup barrier for code whose waves talk through LDS only.  __syncthreads() also waits for every global store the
+// wave has in flight (it is a fence for all memory): after a burst of stores that is the whole trip to HBM, per round.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); vmcnt and expcnt left alone
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // Home slot of a key in the global table = the top bits of the 32-bit hash whose top bits also name the key's partition
 // in the many-groups mode (below them, bits of `h` in a table of more than 2^32 slots): the keys of one partition live
 // in one stretch of the table, which a partition's flush then walks instead of touching lines all over it.

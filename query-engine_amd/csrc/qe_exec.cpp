@@ -25,6 +25,7 @@ struct Iter {
   virtual ~Iter() {}
   virtual bool next(Batch &out) = 0;  // false = exhausted
   virtual void reset() = 0;           // start over (used when a group table has to grow)
+  virtual int64_t batches_ahead() const { return 0; }  // how many batches next() will hand out in all; 0 = not known
 };
 
 struct ScanIter : Iter {
@@ -47,6 +48,7 @@ struct ScanIter : Iter {
     return true;
   }
   void reset() override { cur = 0; }
+  int64_t batches_ahead() const override { return parquet ? (int64_t)(end - first) : (int64_t)batches.size(); }
 };
 
 // A run of Projection / Selection operators over one source, expressed over the
@@ -960,6 +962,33 @@ struct SpillPlan {
   int bits = 0, blocks = 0;
   BufferPtr cell_buf, cell1_buf, scan_buf;
   bool counted = false;  // the first pass filled the cell table and the log's length itself
+  // The log can wait for the logs of the batches that follow and be partitioned and aggregated together with them
+  // (SpillGroup): a first pass that counts its rows per partition itself, a log of pairs, the one-pass scatter.
+  bool groupable = false, grouped = false;
+  bool direct = false;  // the launch partitions its rows itself (AggSpill::direct_cap): `keys` are the stretches, `cell_buf` the rows in each
+};
+
+// The logs of consecutive batches of one aggregation, partitioned and aggregated together.  Every first pass ends by
+// flushing its workgroups' tables, every partition-wise aggregate by flushing one table per partition - about a million
+// groups each time with a million keys, whatever the number of rows in between - and the partition passes wait for the
+// host to size their buffers.  Batch by batch that is paid per batch; here the first passes run back to back, each
+// into its own log and its own block of columns of ONE cell table [partition][launch][workgroup], and a single scan,
+// one wait, one scatter per log into one partitioned copy and one partition-wise aggregate follow when the group is
+// full or the result is asked for.
+struct SpillGroup {
+  int bits = 0, blocks = 0, slots = 0, n_accs = 0;
+  BufferPtr cell_buf, scan_buf, ctrl;  // ctrl: [0] rows logged by the group's launches, [1] the partition ticket, [2] rows they selected, [3] rows partitioned directly
+  struct Item {
+    BufferPtr keys, vals, counts;
+    AggSpill spill;
+    int waves;
+    bool direct;  // no log: `keys` holds the rows as the first pass partitioned them, `counts` the rows per (partition, workgroup) stretch
+  };
+  std::vector<Item> items;
+  uint64_t log_rows = 0;  // capacity of the logs held, in rows
+  VmAcc accs[VM_MAX_ACCS];
+  uint8_t acc_col[VM_MAX_ACCS];
+  AggTable table{};
 };
 
 // Partitions of the second phase: as few as keep a partition's distinct keys within 5/8 of its LDS table.
@@ -985,7 +1014,8 @@ static bool spill_enabled() {
 }
 
 // Decides on the mode for one launch and, when on, attaches the log buffers to `args`.
-static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &bspec, AggArgs &args, int64_t group_hint) {
+static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &bspec, AggArgs &args, int64_t group_hint, bool may_group = false,
+                            bool want_direct = false) {
   SpillPlan sp;
   std::memset(args.spill_col, 0xff, sizeof(args.spill_col));
   std::memset(sp.acc_col, 0xff, sizeof(sp.acc_col));
@@ -1046,13 +1076,6 @@ static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &b
     return e ? atoi(e) != 0 : true;
   }();
   a.pairs = pairs_on && a.n_inputs == 1 ? 1u : 0u;
-  sp.keys = device_buffer(ctx, a.capacity * (a.pairs ? 16 : 8) + 64);
-  sp.vals = device_buffer(ctx, a.pairs ? 64 : a.capacity * 8 * a.n_inputs + 64);
-  sp.counts = device_buffer(ctx, (size_t)sp.waves * 4 + 64);
-  QE_HIP(hipMemsetAsync(sp.counts->ptr, 0, (size_t)sp.waves * 4, ctx->stream));
-  a.keys = (unsigned long long *)sp.keys->ptr;
-  a.vals = (unsigned long long *)sp.vals->ptr;
-  a.counts = (uint32_t *)sp.counts->ptr;
   // the partition passes' geometry and tables, now: a first pass that can counts its logged rows per partition itself
   static int forced_blocks = [] {
     const char *e = getenv("QE_SPILL_BLOCKS");
@@ -1060,19 +1083,48 @@ static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &b
   }();
   sp.bits = spill_partition_bits(args.n_accs, group_hint);
   sp.blocks = forced_blocks > 0 ? forced_blocks : ctx->dev.cus;
-  const size_t cells = spill_cells(sp.bits, sp.blocks), cells1 = spill_cells(spill_level1_bits(sp.bits), sp.blocks);
-  sp.cell_buf = device_buffer(ctx, (cells + 1) * 4 + 64);
-  sp.cell1_buf = device_buffer(ctx, (cells1 + 1) * 4 + 64);
-  sp.scan_buf = device_buffer(ctx, scan_scratch_elems((int64_t)cells) * 4 + 64);
-  QE_HIP(hipMemsetAsync(ctx->counters + 2, 0, 2 * sizeof(unsigned long long), ctx->stream));  // log length, partition ticket
+  if (want_direct && may_group && a.pairs && args.block_threads == (uint32_t)AGG_WIDE_THREADS && grid == sp.blocks && sp.blocks == ctx->dev.cus &&
+      (args.tune & 2u) && sp.blocks * PART_MAX_DIRECT <= PART_MAX_DIRECT_UNITS && aggregate_direct_available(args, ctx->dev, sp.bits)) {
+    // no log: one stretch of pairs per (partition, workgroup), the rows in each counted into a table of its own
+    a.direct_cap = aggregate_direct_stretch_rows(args.n_rows, sp.bits, sp.blocks);
+    const size_t stretches = spill_cells(sp.bits, sp.blocks);
+    sp.keys = device_buffer(ctx, stretches * a.direct_cap * 16 + 256);
+    sp.cell_buf = device_buffer(ctx, stretches * 4 + 64);
+    a.keys = (unsigned long long *)sp.keys->ptr;
+    a.vals = nullptr;
+    a.capacity = (uint64_t)stretches * a.direct_cap;
+    args.cells = (int32_t *)sp.cell_buf->ptr;
+    args.cells_stride = (uint32_t)sp.blocks;
+    args.cell_bits = sp.bits;
+    sp.direct = sp.groupable = sp.on = true;
+    return sp;
+  }
+  sp.keys = device_buffer(ctx, a.capacity * (a.pairs ? 16 : 8) + 64);
+  sp.vals = device_buffer(ctx, a.pairs ? 64 : a.capacity * 8 * a.n_inputs + 64);
+  sp.counts = device_buffer(ctx, (size_t)sp.waves * 4 + 64);
+  QE_HIP(hipMemsetAsync(sp.counts->ptr, 0, (size_t)sp.waves * 4, ctx->stream));
+  a.keys = (unsigned long long *)sp.keys->ptr;
+  a.vals = (unsigned long long *)sp.vals->ptr;
+  a.counts = (uint32_t *)sp.counts->ptr;
   static const int fuse_count = [] {
     const char *e = getenv("QE_SPILL_FUSED_COUNT");  // 0: off; 2 (timing experiments): the segment runs without the fused count
     return e ? atoi(e) : 1;
   }();
-  if (fuse_count && args.block_threads == (uint32_t)AGG_WIDE_THREADS && grid == sp.blocks) {
-    // one first-pass workgroup per column of the cell table: workgroup b's waves own segments [16 b, 16 b + 16)
-    a.seg_chunk = AGG_WIDE_THREADS / 64;
-    if (fuse_count != 2) {
+  const bool fused = fuse_count && args.block_threads == (uint32_t)AGG_WIDE_THREADS && grid == sp.blocks;
+  static const bool group_on = [] {
+    const char *e = getenv("QE_SPILL_GROUP");  // 0: every batch's log is partitioned and aggregated by itself
+    return e ? atoi(e) != 0 : true;
+  }();
+  if (fused) a.seg_chunk = AGG_WIDE_THREADS / 64;  // one first-pass workgroup per column of the cell table: workgroup b's waves own segments [16 b, 16 b + 16)
+  sp.groupable = may_group && group_on && fused && fuse_count != 2 && a.pairs && spill_onepass_available(sp.bits, a.n_inputs) &&
+                 aggregate_counts_partitions(args, ctx->dev, sp.bits);
+  if (!sp.groupable) {
+    const size_t cells = spill_cells(sp.bits, sp.blocks), cells1 = spill_cells(spill_level1_bits(sp.bits), sp.blocks);
+    sp.cell_buf = device_buffer(ctx, (cells + 1) * 4 + 64);
+    sp.cell1_buf = device_buffer(ctx, (cells1 + 1) * 4 + 64);
+    sp.scan_buf = device_buffer(ctx, scan_scratch_elems((int64_t)cells) * 4 + 64);
+    QE_HIP(hipMemsetAsync(ctx->counters + 2, 0, 2 * sizeof(unsigned long long), ctx->stream));  // log length, partition ticket
+    if (fused && fuse_count != 2) {
       args.cells = (int32_t *)sp.cell_buf->ptr;
       args.cells_total = ctx->counters + 2;
       args.cell_bits = sp.bits;
@@ -1116,7 +1168,7 @@ static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &
   if (onepass) {
     out_keys = device_buffer(ctx, stride * 16 + 256);
     ctx->prof_begin("qe_spill_scatter_onepass_kernel");
-    QE_HIP(launch_spill_scatter_onepass(args.spill, sp.waves, bits, blocks, cell, out_keys->ptr, ctx->stream));
+    QE_HIP(launch_spill_scatter_onepass(args.spill, sp.waves, bits, blocks, cell, blocks, out_keys->ptr, ctx->stream));
     ctx->prof_end();
   } else {
     out_keys = device_buffer(ctx, stride * 8 + 64);
@@ -1194,6 +1246,12 @@ static Batch batch_prefix(const Batch &b, int64_t rows) {
   return p;
 }
 
+// Thrown by AggState::finish when a first pass that partitions its rows itself met a (partition, workgroup) stretch
+// too small for its rows - keys far from evenly spread, which the rows it was chosen by did not show: the caller starts
+// over with `direct_off` set, every batch through the table-and-log first pass.
+struct NeedsLogPath {};
+constexpr int64_t DIRECT_PROBE_ROWS = (int64_t)1 << 20;  // rows of the first large batch that choose between the two first passes
+
 struct AggState {
   Context *ctx = nullptr;
   bool strict = false;
@@ -1253,6 +1311,178 @@ struct AggState {
   int64_t last_start_hint = 0, learned_hint = 0;
   int64_t effective_hint() const { return std::max(cap_hint, learned_hint); }
 
+  // High-cardinality mode: the logs of the batches seen since the last partition passes (SpillGroup), and how many
+  // batches the caller expects (sizes the group's cell table; 0 = not known).
+  SpillGroup spill_group;
+  int expected_batches = 0;
+  // Which first pass the many-groups mode runs: 0 not chosen yet, 1 the one with a table and a log, 2 the one that
+  // partitions its rows itself.  Chosen by the share of the first large batch's first rows that miss the table
+  // (update); `direct_off`: never the second (an aggregation that started over after NeedsLogPath).
+  int direct_mode = 0;
+  bool direct_off = false;
+  BufferPtr direct_overflow;  // set on the device when a stretch was too small; read with the group count at the end
+
+  void spill_attach(SpillPlan &sp, AggArgs &args) {
+    SpillGroup &g = spill_group;
+    if (!g.items.empty() && (g.bits != sp.bits || g.blocks != sp.blocks || g.n_accs != args.n_accs || (int)g.items.size() >= g.slots ||
+                             g.log_rows + args.spill.capacity >= (1ull << 31)))
+      spill_flush();
+    if (g.items.empty()) {
+      g.bits = sp.bits;
+      g.blocks = sp.blocks;
+      g.n_accs = args.n_accs;
+      g.slots = std::max(1, std::min(expected_batches > 0 ? expected_batches : 4, 8));
+      const size_t cells = spill_cells(g.bits, g.blocks * g.slots);
+      g.cell_buf = device_buffer(ctx, (cells + 1) * 4 + 64);
+      g.scan_buf = device_buffer(ctx, scan_scratch_elems((int64_t)cells) * 4 + 64);
+      g.ctrl = device_buffer(ctx, 256);
+      QE_HIP(hipMemsetAsync(g.cell_buf->ptr, 0, (cells + 1) * 4, ctx->stream));  // (a slot no launch fills holds no rows)
+      QE_HIP(hipMemsetAsync(g.ctrl->ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
+      g.log_rows = 0;
+    }
+    if (sp.direct) {
+      if (!direct_overflow) {
+        direct_overflow = device_buffer(ctx, 256);
+        QE_HIP(hipMemsetAsync(direct_overflow->ptr, 0, 8, ctx->stream));
+      }
+      args.spill.counts = (uint32_t *)direct_overflow->ptr;
+      args.cells_total = (unsigned long long *)g.ctrl->ptr + 3;
+    } else {
+      args.cells = (int32_t *)g.cell_buf->ptr + g.items.size() * (size_t)g.blocks;
+      args.cells_stride = (uint32_t)(g.slots * g.blocks);
+      args.cells_total = (unsigned long long *)g.ctrl->ptr;
+      args.cell_bits = sp.bits;
+    }
+    sp.grouped = true;
+  }
+
+  void spill_push(const SpillPlan &sp, const AggArgs &args) {
+    SpillGroup &g = spill_group;
+    if (!sp.counted) fail(QE_ERR_INTERNAL, "a first pass that was to count its logged rows per partition did not");
+    g.items.push_back(SpillGroup::Item{sp.keys, sp.vals, sp.direct ? sp.cell_buf : sp.counts, args.spill, sp.waves, sp.direct});
+    g.log_rows += args.spill.capacity;
+    for (int i = 0; i < args.n_accs; ++i) {
+      g.accs[i] = args.accs[i];
+      g.acc_col[i] = sp.acc_col[i];
+    }
+    g.table = args.table;
+    // (the logs are sized for every row of their batch: no more of them at a time than a sixth of the card's memory holds)
+    if ((int)g.items.size() >= g.slots || g.log_rows * 16 > ctx->dev.total_mem / 6) spill_flush();
+  }
+
+  // The partition passes over the group's batches: for the logs one scan of the cell table, one wait for the number of
+  // rows and a scatter per log into one partitioned copy; then one partition-wise aggregate over that copy and the
+  // stretches of the batches that were partitioned directly (which need no pass and no wait here).
+  void spill_flush() {
+    SpillGroup &g = spill_group;
+    if (g.items.empty()) return;
+    ctx->bind();
+    ensure_counters(ctx);
+    const int stride = g.slots * g.blocks;
+    const size_t cells = spill_cells(g.bits, stride);
+    int32_t *cell = (int32_t *)g.cell_buf->ptr;
+    unsigned long long *total = (unsigned long long *)g.ctrl->ptr;
+    int n_logs = 0, n_direct = 0;
+    for (auto &it : g.items) (it.direct ? n_direct : n_logs)++;
+    int64_t m = 0;
+    BufferPtr out;
+    static const bool verbose = getenv("QE_SPILL_VERBOSE") != nullptr;
+    if (n_logs > 0) {
+      QE_HIP(launch_exclusive_scan_i32(cell, (int64_t)cells, (int32_t *)g.scan_buf->ptr, ctx->stream));
+      QE_HIP(hipMemcpyAsync(ctx->host_counters + 2, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+      ctx->sync();
+      m = (int64_t)ctx->host_counters[2];
+      if (m >= ((int64_t)1 << 31)) fail(QE_ERR_INTERNAL, "the logs of a group of batches hold more rows than the cell table can count");
+    }
+    if (verbose)
+      fprintf(stderr, "qe_gpu: high-cardinality mode: %lld rows logged by %d launches, %d launches partitioned directly, %d partitions\n", (long long)m, n_logs,
+              n_direct, 1 << g.bits);
+    const uint64_t rows = ((uint64_t)m + 63) & ~63ull;
+    if (m > 0) {
+      out = device_buffer(ctx, rows * 16 + 256);
+      for (size_t l = 0; l < g.items.size(); ++l) {
+        if (g.items[l].direct) continue;
+        ctx->prof_begin("qe_spill_scatter_onepass_kernel");
+        QE_HIP(launch_spill_scatter_onepass(g.items[l].spill, g.items[l].waves, g.bits, g.blocks, cell + l * (size_t)g.blocks, stride, out->ptr, ctx->stream));
+        ctx->prof_end();
+      }
+    }
+    if (m > 0 || n_direct > 0) {
+      PartArgs pa{};
+      pa.keys = m > 0 ? (const unsigned long long *)out->ptr : nullptr;
+      pa.vals = nullptr;
+      pa.interleaved = 1;
+      pa.capacity = rows;
+      pa.offsets = cell;
+      pa.n_parts = 1 << g.bits;
+      pa.stride = stride;
+      pa.total = m;
+      for (int i = 0; i < g.n_accs; ++i) {
+        pa.accs[i] = g.accs[i];
+        pa.acc_col[i] = g.acc_col[i];
+      }
+      pa.n_accs = g.n_accs;
+      pa.n_inputs = (int)g.items[0].spill.n_inputs;
+      pa.table = g.table;
+      pa.lds_cap = partitioned_lds_slots(g.n_accs);
+      pa.lds_limit = pa.lds_cap - pa.lds_cap / 4;
+      pa.ticket = total + 1;
+      pa.direct_blocks = g.blocks;
+      for (auto &it : g.items)
+        if (it.direct) {
+          if (pa.n_direct >= PART_MAX_DIRECT) fail(QE_ERR_INTERNAL, "more directly partitioned batches in a group than the partition-wise aggregate takes");
+          pa.direct[pa.n_direct++] = PartDirect{it.spill.keys, (const int32_t *)it.counts->ptr, it.spill.direct_cap, (uint32_t)g.blocks};
+        }
+      ctx->prof_begin("qe_aggregate_partitioned_kernel");
+      QE_HIP(launch_aggregate_partitioned(pa, ctx->dev, ctx->stream));
+      ctx->prof_end();
+    }
+    // (the buffers go back to the pool: any later use is ordered behind these kernels on the stream)
+    g.items.clear();
+    g.cell_buf.reset();
+    g.scan_buf.reset();
+    g.ctrl.reset();
+    g.log_rows = 0;
+  }
+
+  // Chooses between the two first passes of the many-groups mode: the first rows of the batch go through the one with
+  // a table and a log - results thrown away: no flush of the tables, a log that the batch's real launch overwrites -
+  // and the share of the selected rows that missed the table decides.  `args` is the batch's launch as planned for that
+  // first pass (log attached).
+  void choose_first_pass(const AggArgs &args, const SpillPlan &sp) {
+    direct_mode = 1;
+    AggArgs probe = args;
+    static const int64_t probe_rows = [] {
+      const char *e = getenv("QE_AGGREGATE_DIRECT_PROBE_ROWS");
+      return e && atoll(e) > 0 ? (int64_t)atoll(e) : DIRECT_PROBE_ROWS;
+    }();
+    probe.n_rows = std::min<int64_t>(args.n_rows, probe_rows);
+    probe.tune |= 4u;  // the workgroups' tables are not flushed
+    const size_t cells = spill_cells(sp.bits, sp.blocks);
+    BufferPtr cell_buf = device_buffer(ctx, (cells + 1) * 4 + 64), ctrl = device_buffer(ctx, 256);
+    QE_HIP(hipMemsetAsync(ctrl->ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    probe.cells = (int32_t *)cell_buf->ptr;
+    probe.cells_stride = (uint32_t)sp.blocks;
+    probe.cells_total = (unsigned long long *)ctrl->ptr;
+    probe.cell_bits = sp.bits;
+    bool counted = false;
+    const char *kname = "qe_aggregate_kernel";
+    ctx->prof_begin(kname, probe.n_rows);
+    QE_HIP(launch_aggregate(probe, ctx->dev, ctx->stream, &kname, &counted));
+    ctx->prof_end(kname);
+    QE_HIP(hipMemcpyAsync(ctx->host_counters + 24, ctrl->ptr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    if (!counted) return;
+    const double logged = (double)ctx->host_counters[24], selected = (double)ctx->host_counters[26];
+    static const double threshold = [] {
+      const char *e = getenv("QE_AGGREGATE_DIRECT_MISS_SHARE");
+      return e && atof(e) > 0 ? atof(e) : 0.85;
+    }();
+    if (selected > 0 && logged >= threshold * selected) direct_mode = 2;
+    static const bool verbose = getenv("QE_SPILL_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "qe_gpu: high-cardinality mode: %.0f of %.0f selected rows logged: %s first pass\n", logged, selected, direct_mode == 2 ? "partitioning" : "logging");
+  }
+
   // Fresh table for about `hint` groups.
   void start(int64_t hint) {
     if (last_start_hint > 0 && hint > last_start_hint) learned_hint = std::max(learned_hint, hint);
@@ -1274,6 +1504,8 @@ struct AggState {
         p->groups = groups;
         p->mode = mode;
         p->cap_hint = effective_hint();
+        p->expected_batches = expected_batches;
+        p->direct_off = direct_off;
         p->emit_row_number = true;
         for (int w = 0; i < aggs.size() && (w == 0 || w + acc_weight(aggs[i]) <= PART_ACC_BUDGET); ++i) {
           w += acc_weight(aggs[i]);
@@ -1284,6 +1516,9 @@ struct AggState {
       }
     }
     have_table = false;
+    spill_group = SpillGroup();  // (logs of an aggregation that starts over are dropped with its table)
+    direct_mode = 0;
+    direct_overflow.reset();
     spec = AggSpec();
     table = AggTable{};
     table_buf.reset();
@@ -1507,12 +1742,39 @@ struct AggState {
     args.n_rows = in.rows;
     args.lds_cap = aggregate_lds_slots(args, ctx->dev, effective_hint(), false);
     args.lds_limit = args.lds_cap - args.lds_cap / 4;
-    SpillPlan sp = plan_spill(ctx, schema, bspec, args, effective_hint());
+    SpillPlan sp = plan_spill(ctx, schema, bspec, args, effective_hint(), true, direct_mode == 2);
+    if (sp.on && sp.groupable && !sp.direct && direct_mode == 0 && !direct_off && in.rows >= 8 * DIRECT_PROBE_ROWS && sp.blocks == ctx->dev.cus &&
+        aggregate_direct_available(args, ctx->dev, sp.bits)) {
+      choose_first_pass(args, sp);
+      if (direct_mode == 2) {
+        AggArgs again = args;
+        again.spill = AggSpill{};
+        again.block_threads = 0;
+        again.tune = 0;
+        again.lds_cap = aggregate_lds_slots(again, ctx->dev, effective_hint(), false);
+        again.lds_limit = again.lds_cap - again.lds_cap / 4;
+        SpillPlan direct = plan_spill(ctx, schema, bspec, again, effective_hint(), true, true);
+        if (direct.direct) {  // (else: the log path as planned)
+          args = again;
+          sp = direct;
+        }
+      }
+    }
+    if (sp.on && sp.groupable) spill_attach(sp, args);
+    else spill_flush();  // (a launch that goes another way: what is pending first, so that the table sees the batches in order)
     const char *kname = "qe_aggregate_kernel";
     ctx->prof_begin(kname, in.rows);
-    QE_HIP(launch_aggregate(args, ctx->dev, ctx->stream, &kname, &sp.counted));
+    if (sp.direct) {
+      QE_HIP(launch_aggregate_direct(args, ctx->dev, ctx->stream, &kname));
+      sp.counted = true;
+    } else {
+      QE_HIP(launch_aggregate(args, ctx->dev, ctx->stream, &kname, &sp.counted));
+    }
     ctx->prof_end(kname);
-    if (sp.on) aggregate_spilled(ctx, sp, args, effective_hint());
+    if (sp.on) {
+      if (sp.grouped) spill_push(sp, args);
+      else aggregate_spilled(ctx, sp, args, effective_hint());
+    }
     if (!comp.keepalive.empty()) ctx->sync();
   }
 
@@ -1688,6 +1950,7 @@ struct AggState {
     if (!parts.empty()) return finish_parts(result);
     // empty input: `iter.next().ok_or(Error::EmptyHashmapForAggregate)` (physical_plan/mod.rs:377)
     if (!have_table) fail(QE_ERR_EMPTY_HASHMAP_FOR_AGGREGATE, "The hashmap for aggregation is empty.");
+    spill_flush();  // the logged rows of the last batches
     // Small tables: the output columns are sized for every slot and the finalize pass is queued
     // before the group count is known, so that one trip to the host serves both.  Large tables
     // read the count first and allocate exactly.
@@ -1697,8 +1960,10 @@ struct AggState {
     // (the word an order-independent sum's kernels set when a value did not fit the scale travels with the control words)
     auto queue_scale_check = [&] {
       if (fix_overflow) QE_HIP(hipMemcpyAsync(ctx->host_counters + 20, fix_overflow->ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+      if (direct_overflow) QE_HIP(hipMemcpyAsync(ctx->host_counters + 21, direct_overflow->ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     };
     auto scale_check = [&] {
+      if (direct_overflow && ctx->host_counters[21]) throw NeedsLogPath{};  // (rows are missing: nothing else about this result matters)
       if (fix_overflow && ctx->host_counters[20]) throw NeedsExactScales{};
     };
     if (!eager) {
@@ -1774,6 +2039,7 @@ struct AggIter : Iter {
     st.cap_hint = cap_hint;
     int64_t hint = cap_hint > 0 ? cap_hint : 32768;
     for (int attempt = 0; attempt < 7; ++attempt) {
+      st.expected_batches = (int)std::min<int64_t>(s.src->batches_ahead(), 1 << 20);
       st.start(hint);
       s.src->reset();
       Batch in;
@@ -1790,6 +2056,9 @@ struct AggIter : Iter {
         }
       } catch (const NeedsExactScales &) {
         st.fix_exact = true;  // a value did not fit the scale the first rows suggested: once more, every batch's scale found first
+        continue;
+      } catch (const NeedsLogPath &) {
+        st.direct_off = true;  // keys far from evenly spread: once more, every batch through the first pass with a table and a log
         continue;
       }
       // grow (a full table says little about how many groups there are: a big step, up to the largest table) and run the aggregation again
@@ -2199,6 +2468,7 @@ qe_status qe_context_create(int32_t device, void *stream, qe_context **out) {
     ctx->c.device = device;
     ctx->c.dev.cus = prop.multiProcessorCount;
     ctx->c.dev.max_lds = (int)prop.sharedMemPerBlock;
+    ctx->c.dev.total_mem = (uint64_t)prop.totalGlobalMem;
     ctx->c.dev.device = device;
     ctx->c.dev.jit = jit_default_mode();
     if (stream) {
@@ -2686,6 +2956,9 @@ qe_status qe_agg_finalize(qe_agg_state *state, qe_batch **out) {
         }
       } catch (const NeedsExactScales &) {
         state->st.fix_exact = true;  // an order-independent sum met a value beyond its scale: everything once more, scales found first
+        grow = false;
+      } catch (const NeedsLogPath &) {
+        state->st.direct_off = true;  // a first pass that partitions directly met keys far from evenly spread: everything once more, through the log
         grow = false;
       }
       // the table overflowed: a larger one, and everything seen so far folded in again

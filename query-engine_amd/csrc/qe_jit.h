@@ -20,7 +20,8 @@ enum JitMode : int {
 
 // JIT_AGGREGATE_SPILL: the high-cardinality mode's first pass (qe_aggregate_spill_static) of an aggregate shape; its
 // SpecFields carry one more signature word than the plain aggregate's (spec_fields_spill), so the two never share an entry.
-enum JitKind : int { JIT_PROJECT = 0, JIT_FILTER = 1, JIT_AGGREGATE = 2, JIT_AGGREGATE_SPILL = 3 };
+// JIT_AGGREGATE_DIRECT: that mode's first pass that partitions its rows itself (qe_aggregate_direct_static; spec_fields_direct).
+enum JitKind : int { JIT_PROJECT = 0, JIT_FILTER = 1, JIT_AGGREGATE = 2, JIT_AGGREGATE_SPILL = 3, JIT_AGGREGATE_DIRECT = 4 };
 
 // Launches the run-time compiled kernel for this shape if there is one (or, in JIT_SYNC mode,
 // after compiling it).  Returns false when the caller should use the interpreter instead: shape

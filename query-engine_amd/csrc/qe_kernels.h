@@ -14,6 +14,7 @@ struct DeviceInfo {
   int device = 0;
   int jit = 0;               // JitMode: compile such a kernel at run time when none was built ahead
   int64_t jit_min_rows = 1 << 22;  // ... for batches of at least this many rows (background mode)
+  uint64_t total_mem = 0;          // bytes of device memory
 };
 
 // Unfiltered projection: every expression of `args` evaluated for every row.
@@ -34,6 +35,15 @@ hipError_t launch_aggregate(const AggArgs &args, const DeviceInfo &dev, hipStrea
 uint32_t aggregate_lds_slots(const AggArgs &args, const DeviceInfo &dev, int64_t group_hint, bool wide);
 // Whether a kernel that can be launched wide exists for this shape right now.
 bool aggregate_wide_available(const AggArgs &args, const DeviceInfo &dev);
+// The many-groups first pass that partitions its rows itself (AggSpill::direct_cap; qe_aggregate_direct_static):
+// whether a kernel for this shape can be launched right now, the launch (workgroups = dev.cus, one column of the
+// cell table each), and the rows a (partition, workgroup) stretch must hold for a batch of `n_rows`.
+bool aggregate_direct_available(const AggArgs &args, const DeviceInfo &dev, int bits);
+hipError_t launch_aggregate_direct(const AggArgs &args, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name = nullptr);
+uint32_t aggregate_direct_stretch_rows(int64_t n_rows, int bits, int blocks);
+// Whether launch_aggregate, given a cell table of 2^bits partitions (AggArgs::cells), will run the many-groups first
+// pass that counts its logged rows per partition itself (the launch then reports `counted`).
+bool aggregate_counts_partitions(const AggArgs &args, const DeviceInfo &dev, int bits);
 
 // High-cardinality mode, second phase (see AggSpill): partition the spill log by key hash
 // (count, scan by the caller, move), then aggregate partition by partition.
@@ -51,7 +61,8 @@ hipError_t launch_aggregate_partitioned(const PartArgs &args, const DeviceInfo &
 // The scatter in one pass: (key, value) pairs of 16 bytes, written a whole 128-byte line at a time.  For logs with at most
 // one value column and at most 512 partitions; `dst_rows` holds 16 bytes per logged row.
 bool spill_onepass_available(int bits, uint32_t n_inputs);
-hipError_t launch_spill_scatter_onepass(const AggSpill &sp, int n_segments, int bits, int blocks, const int32_t *dst_cells, void *dst_rows, hipStream_t stream);
+hipError_t launch_spill_scatter_onepass(const AggSpill &sp, int n_segments, int bits, int blocks, const int32_t *dst_cells, int cells_stride, void *dst_rows,
+                                        hipStream_t stream);
 // Workgroups launch_aggregate will use for these arguments (sizes the per-wave spill regions).
 int aggregate_grid(const AggArgs &args, const DeviceInfo &dev);
 
@@ -146,7 +157,7 @@ hipError_t launch_count_zero_bits(const uint32_t *bitmap, int64_t n, unsigned lo
 bool static_launch_project(const ProjectArgs &args, int grid, hipStream_t stream, hipError_t *err, const char **kernel_name);
 bool static_launch_filter(const FilterArgs &args, int cus, hipStream_t stream, hipError_t *err, const char **kernel_name);
 bool static_launch_aggregate(const AggArgs &args, int grid, int block_threads, size_t lds_bytes, hipStream_t stream, hipError_t *err,
-                             const char **kernel_name, bool spill_first_pass = false);
+                             const char **kernel_name, int first_pass = 0);  // first_pass: 0 the aggregate kernel, 1 / 2 the many-groups first pass that logs / partitions
 bool static_has_aggregate(const AggArgs &args);
 int static_kernel_count();
 const char *static_kernel_name(int i);

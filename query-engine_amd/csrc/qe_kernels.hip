@@ -15,6 +15,7 @@
 // kernel instantiates the interpreter ONCE, rare operations share one out-of-line-style copy
 // that works on temporaries, and per-row work that is more than a few instructions long runs in
 // a rolled loop that rotates the four row registers instead of being unrolled four times.
+#include <cmath>
 #include <cstdlib>
 
 #include "qe_device.h"
@@ -238,22 +239,6 @@ constexpr int SCATTER_MAX_STAGES = 512;
 constexpr int SCATTER_ROWS = 4;       // rows per thread and round
 constexpr int SCATTER_MAX_INPUTS = 8;  // = SPILL_MAX_INPUTS of the host
 
-// A logged row with one value column, and its streaming load as one 16-byte access (two 8-byte loads of the halves
-// each touch every line of a wave's stretch).
-struct alignas(16) KeyVal { unsigned long long key, val; };
-typedef unsigned long long qe_ull2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ KeyVal load_pair_streaming(const KeyVal *p) {
-  const qe_ull2 v = __builtin_nontemporal_load((const qe_ull2 *)p);
-  KeyVal r;
-  r.key = v.x;
-  r.val = v.y;
-  return r;
-}
-
-// Partition of a key: the top bits of the 32-bit hash whose low bits pick the slot in the LDS tables (three 32-bit
-// multiplies; a 64-bit mixer costs several times that, per row and pass).
-__device__ __forceinline__ uint32_t partition_of(unsigned long long key, int bits) { return hash32(key) >> (32 - bits); }
-
 __global__ __launch_bounds__(PART_THREADS) void qe_spill_count_kernel(AggSpill sp, int n_segments, int bits, int32_t *cells, unsigned long long *total) {
   __shared__ uint32_t s_cell[1 << PART_MAX_BITS];
   const int P = 1 << bits;
@@ -304,15 +289,6 @@ struct ScatterArgs {
   uint64_t dst_stride;
   uint32_t n_inputs;
 };
-
-// Workgroup barrier for code whose waves talk through LDS only.  __syncthreads() also waits for every global store the
-// wave has in flight (it is a fence for all memory): after a burst of stores that is the whole trip to HBM, per round.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); vmcnt and expcnt left alone
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
 
 // Dynamic LDS: keys[stages * depth], then vals[n_inputs][stages * depth].
 __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_kernel(const ScatterArgs A) {
@@ -515,9 +491,10 @@ struct OnePassArgs {
   AggSpill sp;               // the log: keys, one value column (or none), per-segment counts
   int n_segments;
   int bits;                  // partitions = 1 << bits
-  const int32_t *dst_cells;  // scanned cells [p * blocks + b]: first row of this workgroup's rows of partition p
+  const int32_t *dst_cells;  // scanned cells [p * cells_stride + b]: first row of this workgroup's rows of partition p
   KeyVal *dst;               // the partitioned rows
   uint32_t n_inputs;         // 0 or 1
+  uint32_t cells_stride;     // columns in a row of the cell table (the logs of several first-pass launches partitioned together: a block of columns each)
 };
 
 __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_onepass_kernel(const OnePassArgs A) {
@@ -534,7 +511,7 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_onepass_kernel(
   auto BAR = [&]() { lds_barrier(); };
 
   for (int p = threadIdx.x; p < P; p += blockDim.x) {
-    const uint64_t base = (uint64_t)(uint32_t)A.dst_cells[(size_t)p * gridDim.x + blockIdx.x];
+    const uint64_t base = (uint64_t)(uint32_t)A.dst_cells[(size_t)p * A.cells_stride + blockIdx.x];
     s_dst0[p] = base & ~7ull;
     s_uw[p] = (uint32_t)(base & 7ull);
     s_ur[p] = 0;
@@ -658,10 +635,14 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_onepass_kernel(
 
 // One ticket = one partition: all its rows folded into a fresh LDS table, the table flushed into
 // the global one.  A partition holds (groups / partitions) distinct keys, chosen by the host to fit.
+// A partition's rows are its stretch of the partitioned copy (A.keys) and / or the stretches that first passes which
+// partition directly wrote for it, one per source and first-pass workgroup (A.direct).  The waves take them as units
+// from a counter: 256-row steps of the copy (pieces of a 64th of it when there are stretches too), whole stretches.
 __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(const PartArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long lds_raw[];  // (the key slots are read in pairs)
   __shared__ unsigned long long s_ticket;
-  __shared__ uint32_t s_step;  // the current partition's next step of 256 rows that no wave has taken yet
+  __shared__ uint32_t s_unit;  // the current partition's next unit that no wave has taken yet
+  __shared__ int32_t s_direct_count[PART_MAX_DIRECT_UNITS];  // rows in each of the current partition's stretches
   const uint32_t lane = lane_id();
   LdsTable L;
   agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, A.n_accs, false);
@@ -673,34 +654,69 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
   none.base = 0;
   none.cursor = 0;
   none.pairs = 0;
+  const uint32_t direct_units = (uint32_t)A.n_direct * (uint32_t)A.direct_blocks;
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) {
       s_ticket = atomicAdd(A.ticket, 1ull);
-      s_step = 0;
+      s_unit = 0;
       // a global table that has been given up (the host starts over with a larger one): no further partition
       if (__hip_atomic_load(&A.table.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) s_ticket = (unsigned long long)A.n_parts;
     }
-    agg_lds_clear(L, A.accs, A.n_accs);  // ends with a barrier
+    __syncthreads();
     const int64_t p = (int64_t)s_ticket;
+    if (p < A.n_parts)
+      for (uint32_t t = threadIdx.x; t < direct_units; t += blockDim.x) {
+        const PartDirect &d = A.direct[t / (uint32_t)A.direct_blocks];
+        s_direct_count[t] = d.counts[(size_t)p * d.counts_stride + t % (uint32_t)A.direct_blocks];
+      }
+    agg_lds_clear(L, A.accs, A.n_accs);  // ends with a barrier
     if (p >= A.n_parts) break;
     GiveUpWatch watch;
-    const int64_t start = A.offsets[p * A.stride];
-    const int64_t end = p + 1 < A.n_parts ? (int64_t)A.offsets[(p + 1) * A.stride] : A.total;
+    const int64_t start = A.keys ? A.offsets[p * A.stride] : 0;
+    const int64_t end = A.keys ? (p + 1 < A.n_parts ? (int64_t)A.offsets[(p + 1) * A.stride] : A.total) : 0;
+    // units of the copy: steps of 256 rows; with stretches to walk as well, 64 pieces (whole steps each)
+    const int64_t piece = direct_units == 0 ? (int64_t)VM_WAVE_ROWS : ((((end - start) + 63) / 64 + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS) * VM_WAVE_ROWS;
+    const uint32_t copy_units = piece > 0 ? (uint32_t)((end - start + piece - 1) / piece) : 0u;
+    const uint32_t n_units = copy_units + direct_units;
     // The keys and the first value column of a wave's next 256 rows are loaded while it works on the current ones:
     // the work is LDS round trips, one after the other, and a memory round trip on top of every step's would double it.
-    // Steps are taken from a counter, not dealt out in turn: the sixteen waves do not run at one pace (the oldest wave
+    // Units are taken from a counter, not dealt out in turn: the sixteen waves do not run at one pace (the oldest wave
     // of a SIMD is served first; dealt equal shares, wave 0 stood a fifth of a partition's time at the barrier).
+    struct Cursor {
+      const KeyVal *rows;  // the unit's pairs; nullptr: rows of the partitioned copy (A.keys / A.vals)
+      int64_t pos, end;    // the next step's first row, the unit's end
+    };
+    auto next_unit = [&](Cursor &c) -> bool {  // (wave-uniform)
+      for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&s_unit, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= n_units) return false;
+        if (t < copy_units) {
+          c.rows = A.interleaved ? (const KeyVal *)A.keys : nullptr;
+          c.pos = start + (int64_t)t * piece;
+          c.end = c.pos + piece < end ? c.pos + piece : end;
+        } else {
+          const uint32_t du = t - copy_units, src = du / (uint32_t)A.direct_blocks, b = du % (uint32_t)A.direct_blocks;
+          const PartDirect &d = A.direct[src];
+          c.rows = (const KeyVal *)d.rows + ((uint64_t)p * (uint32_t)A.direct_blocks + b) * d.cap;
+          c.pos = 0;
+          c.end = s_direct_count[du];
+        }
+        if (c.pos < c.end) return true;
+      }
+    };
     unsigned long long nkey[VM_R], nval[VM_R];
-    auto fetch = [&](int64_t r0) {
+    auto fetch = [&](const Cursor &c) {
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) {
-        const int64_t r = r0 + j * 64 + lane;
+        const int64_t r = c.pos + j * 64 + lane;
         nkey[j] = 0;
         nval[j] = 0;
-        if (r < end) {
-          if (A.interleaved) {
-            const KeyVal kv = load_pair_streaming((const KeyVal *)A.keys + r);
+        if (r < c.end) {
+          if (c.rows) {
+            const KeyVal kv = load_pair_streaming(c.rows + r);
             nkey[j] = kv.key;
             nval[j] = kv.val;
           } else {
@@ -710,54 +726,57 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
         }
       }
     };
-    auto take = [&]() -> int64_t {
-      uint32_t t = 0;
-      if (lane == 0) t = atomicAdd(&s_step, 1u);
-      return start + (int64_t)__builtin_amdgcn_readfirstlane((int)t) * VM_WAVE_ROWS;
-    };
-    int64_t r0 = take(), rn = 0;
-    if (r0 < end) fetch(r0);
-    for (; r0 < end; r0 = rn) {
+    Cursor nxt;
+    nxt.rows = nullptr;
+    nxt.pos = nxt.end = 0;
+    bool have = next_unit(nxt);
+    if (have) fetch(nxt);
+    while (have) {
       if (table_given_up(A.table, watch)) break;
       AggRows G;
       Slot in;
       in.valid = 0xFu;
       uint32_t active = 0;
+      const int64_t r0 = nxt.pos;  // (rows of the copy: where the further value columns of this step are read)
 #pragma unroll
       for (int j = 0; j < VM_R; ++j) {
         G.key[j] = nkey[j];
         in.v[j] = nval[j];
         G.slot[j] = SLOT_NONE;
-        if (r0 + j * 64 + lane < end) active |= 1u << j;
+        if (nxt.pos + j * 64 + lane < nxt.end) active |= 1u << j;
       }
-      rn = take();
-      if (rn < end) fetch(rn);
-      // The common step: 256 rows, every one of which finds (or claims) a slot in the LDS table - by construction a
-      // partition's keys fit it.  No per-row bookkeeping of who goes where: four lookups, then one LDS operation per
-      // row and accumulator.  Anything else (the partition's last rows, a key the table has no room for) takes the
-      // general path below, which looks the rows up again (a lookup changes nothing but the table's key slots).
-      if (r0 + VM_WAVE_ROWS <= end) {
+      nxt.pos += VM_WAVE_ROWS;
+      if (nxt.pos >= nxt.end) have = next_unit(nxt);
+      if (have) fetch(nxt);
+      // The common step: every row finds (or claims) a slot in the LDS table - by construction a partition's keys fit
+      // it.  No per-row bookkeeping of who goes where: four lookups, then one LDS operation per row and accumulator.
+      // Anything else (a key the table has no room for) takes the general path below, which looks the rows up again
+      // (a lookup changes nothing but the table's key slots).
+      {
         int32_t slot[VM_R];
+        uint32_t hit;
         if (A.ablate & 4) {
 #pragma unroll
           for (int j = 0; j < VM_R; ++j) slot[j] = (int32_t)(hash32(G.key[j]) & (L.cap - 1));
+          hit = active;
         } else {
           // a pair of slots a probe (one 16-byte LDS read): half the dependent round trips of the longest probe
           // sequence among the wave's 256 rows, which is what a step waits for
           uint32_t slot8[VM_R];
-          const uint32_t hit = lds_pair_find_or_claim4<false>(L, G.key, 0xFu, LDS_MAX_PROBE / 2, slot8);
+          hit = lds_pair_find_or_claim4<false>(L, G.key, active, LDS_MAX_PROBE / 2, slot8);
 #pragma unroll
-          for (int j = 0; j < VM_R; ++j) slot[j] = ((hit >> j) & 1u) ? (int32_t)(slot8[j] >> 3) : SLOT_LDS_MISS;
+          for (int j = 0; j < VM_R; ++j) slot[j] = (int32_t)(slot8[j] >> 3);
         }
-        if (__ballot((slot[0] | slot[1] | slot[2] | slot[3]) < 0) == 0) {
+        if (__ballot(hit != active) == 0) {
           if (A.ablate & 2) continue;
 #pragma unroll
-          for (int j = 0; j < VM_R; ++j) atomicAdd(&L.rowcnt[slot[j]], 1u);
+          for (int j = 0; j < VM_R; ++j)
+            if ((active >> j) & 1u) atomicAdd(&L.rowcnt[slot[j]], 1u);
 #pragma unroll 1
           for (int v = 0; v < A.n_inputs; ++v) {
-            if (v > 0) {
+            if (v > 0) {  // (logs with several value columns are never pairs: rows of the copy)
 #pragma unroll
-              for (int j = 0; j < VM_R; ++j) in.v[j] = A.vals[(uint64_t)v * A.capacity + r0 + j * 64 + lane];
+              for (int j = 0; j < VM_R; ++j) in.v[j] = ((active >> j) & 1u) ? A.vals[(uint64_t)v * A.capacity + r0 + j * 64 + lane] : 0ull;
             }
 #pragma unroll 1
             for (int a = 0; a < A.n_accs; ++a) {
@@ -769,14 +788,15 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
 #pragma unroll
                 for (int j = 0; j < VM_R; ++j) {
                   const bool nan = in_type == VT_F64 && u2d(in.v[j]) != u2d(in.v[j]);  // NaN is ignored by min / max
-                  if (!nan) {
+                  if (!nan && ((active >> j) & 1u)) {
                     if (op == ACC_MIN) atomicMin(acc + slot[j], (unsigned long long)ord_image(in.v[j], in_type));
                     else atomicMax(acc + slot[j], (unsigned long long)ord_image(in.v[j], in_type));
                   }
                 }
               } else {
 #pragma unroll
-                for (int j = 0; j < VM_R; ++j) acc_apply(acc + slot[j], op, op == ACC_COUNT ? 1ull : in.v[j]);
+                for (int j = 0; j < VM_R; ++j)
+                  if ((active >> j) & 1u) acc_apply(acc + slot[j], op, op == ACC_COUNT ? 1ull : in.v[j]);
               }
             }
           }
@@ -791,10 +811,7 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
       for (int v = 0; v < A.n_inputs; ++v) {
         if (v > 0) {
 #pragma unroll
-          for (int j = 0; j < VM_R; ++j) {
-            const int64_t r = r0 + j * 64 + lane;
-            in.v[j] = r < end ? A.vals[(uint64_t)v * A.capacity + r] : 0ull;
-          }
+          for (int j = 0; j < VM_R; ++j) in.v[j] = ((active >> j) & 1u) ? A.vals[(uint64_t)v * A.capacity + r0 + j * 64 + lane] : 0ull;
         }
 #pragma unroll 1
         for (int a = 0; a < A.n_accs; ++a)
@@ -1660,6 +1677,69 @@ static bool dense_bins_wanted(const AggArgs &args, size_t lds, int grid, const D
   return total <= 64 * 1024 && (size_t)per_cu * (total + 512) <= (size_t)144 * 1024;
 }
 
+// LDS of a wide launch before the partition histogram: the table, then the admission tags of the many-groups mode.
+static size_t wide_lds_before_histogram(const AggArgs &args, uint32_t *door_off) {
+  size_t lds = agg_lds_bytes(args.n_accs, args.lds_cap, agg_tracks_validity(args.accs, args.n_accs));
+  static int door = tuned("QE_AGGREGATE_DOOR", 1);
+  if (door_off) *door_off = 0;
+  if (door != 2 && args.spill.keys != nullptr && lds + 16 + DOOR_ENTRIES * 2 <= (size_t)159 * 1024) {
+    const uint32_t at = (uint32_t)((lds + 15) & ~(size_t)15);
+    if (door_off) *door_off = at;
+    lds = at + DOOR_ENTRIES * 2;
+  }
+  return lds;
+}
+
+static bool spill_kernel_wanted(const AggArgs &args) {
+  // (QE_AGGREGATE_SPILL_KERNEL=2: the general specialised kernel instead of the first pass's own, for comparison)
+  static int lean = tuned("QE_AGGREGATE_SPILL_KERNEL", 1);
+  return lean != 2 && args.spill.keys != nullptr && (args.tune & 2u) != 0;
+}
+
+bool aggregate_counts_partitions(const AggArgs &args, const DeviceInfo &dev, int bits) {
+  (void)dev;
+  if (!aggregate_is_wide(args) || !spill_kernel_wanted(args) || args.spill.seg_chunk != (uint32_t)(AGG_WIDE_THREADS / 64)) return false;
+  const size_t hist_at = (wide_lds_before_histogram(args, nullptr) + 15) & ~(size_t)15;
+  return hist_at + ((size_t)4 << bits) <= (size_t)160 * 1024;
+}
+
+// Rows a (partition, workgroup) stretch holds: the workgroup's expected share of the batch's rows in that partition
+// if every row is selected, eight standard deviations and a few lines on top, whole lines.  Keys spread evenly never
+// need more; keys that do not are what the logging first pass is for.
+uint32_t aggregate_direct_stretch_rows(int64_t n_rows, int bits, int blocks) {
+  const double mean = (double)n_rows / ((double)((int64_t)1 << bits) * (double)blocks);
+  const double rows = mean + 8.0 * std::sqrt(mean) + 64.0;
+  return (uint32_t)(((int64_t)rows + 7) & ~(int64_t)7);
+}
+
+bool aggregate_direct_available(const AggArgs &args, const DeviceInfo &dev, int bits) {
+  static int on = tuned("QE_AGGREGATE_DIRECT", 1);  // 2: off
+  if (on == 2 || !dev.specialised || bits > 9 || (1 << bits) > DIRECT_MAX_PARTS || direct_lds_bytes(bits) > (size_t)160 * 1024) return false;
+  if (static_has_aggregate(args)) return true;
+  if (!jit_wanted(dev, args.n_rows)) return false;
+  return jit_ready(JIT_AGGREGATE_DIRECT, spec_fields_direct(args), dev.jit, true);
+}
+
+hipError_t launch_aggregate_direct(const AggArgs &args_in, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name) {
+  if (args_in.n_rows <= 0) return hipSuccess;
+  if (args_in.spill.direct_cap == 0 || (args_in.spill.direct_cap & 7u) || args_in.cells == nullptr || args_in.cells_total == nullptr ||
+      args_in.spill.counts == nullptr || args_in.cell_bits > 9)
+    return hipErrorInvalidValue;
+  const size_t lds = direct_lds_bytes(args_in.cell_bits);
+  const int grid = dev.cus;
+  hipError_t err;
+  AggArgs args = args_in;
+  static int streaming = tuned("QE_DIRECT_STREAMING_STORES", 1);  // (2.12 -> 2.06 ms per 256 M rows of a million uniform keys)
+  if (streaming == 1) args.tune |= 0x10u;  // (bit 4: complete lines leave as streaming stores)
+#ifdef QE_ABLATE  // timing experiments only (results are wrong): compiled in by a build with -DQE_ABLATE, never in the shipped library
+  static int ablate = tuned("QE_DIRECT_ABLATE", 0);  // 0x200: rows go nowhere, 0x400: lines are not written, 0x800: no rounds either
+  args.tune |= (uint32_t)ablate & 0xe00u;
+#endif
+  if (static_launch_aggregate(args, grid, AGG_WIDE_THREADS, lds, stream, &err, kernel_name, 2)) return err;
+  if (jit_launch(JIT_AGGREGATE_DIRECT, spec_fields_direct(args), &args, dev.jit, dev.device, grid, AGG_WIDE_THREADS, lds, stream, &err, kernel_name)) return err;
+  return hipErrorInvalidConfiguration;
+}
+
 hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipStream_t stream, const char **kernel_name, bool *counted) {
   if (counted) *counted = false;
   if (args_in.n_rows <= 0) return hipSuccess;
@@ -1670,16 +1750,10 @@ hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipSt
   if (aggregate_is_wide(args)) {
     // the caller checked aggregate_wide_available: one of the two specialised routes takes the launch
     hipError_t werr;
-    static int door = tuned("QE_AGGREGATE_DOOR", 1);
-    if (door != 2 && args.spill.keys != nullptr && lds + 16 + DOOR_ENTRIES * 2 <= (size_t)159 * 1024) {
-      args.door_off = (uint32_t)((lds + 15) & ~(size_t)15);
-      lds = args.door_off + DOOR_ENTRIES * 2;
-    }
-    // the wide launch is the high-cardinality mode's first pass: a kernel of its own (QE_AGGREGATE_SPILL_KERNEL=2: the
-    // general specialised kernel instead, for comparison)
+    lds = wide_lds_before_histogram(args, &args.door_off);
+    // the wide launch is the high-cardinality mode's first pass: a kernel of its own
     // Mid-range cardinalities (a few thousand groups, possibly skewed) keep the general kernel, whose hot keys in
     // registers take a dominant key off the LDS atomics.
-    static int lean = tuned("QE_AGGREGATE_SPILL_KERNEL", 1);
     const bool many_groups = args.spill.keys != nullptr && (args.tune & 2u) != 0;
 #ifdef QE_ABLATE  // timing experiments only (results are wrong): compiled in by a build with -DQE_ABLATE, never in the shipped library
     static int no_flush = tuned("QE_SPILL_ABLATE_FLUSH", 0);
@@ -1689,7 +1763,7 @@ hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipSt
 #endif
     static int prio = tuned("QE_SPILL_PRIO", 1);
     if (prio) args.tune |= 8u;  // (bit 3: the waves of a SIMD take the high priority in turn)
-    const bool spill_kernel = lean != 2 && many_groups;
+    const bool spill_kernel = spill_kernel_wanted(args);
     if (many_groups && !spill_kernel) args.tune |= 1u;  // (with many groups the hot keys cost more than they save: 2.67 -> 2.42 ms per 256 M rows)
     // the first pass counts its logged rows per partition when the caller asked for it (args.cells), the launch has one
     // workgroup per column of the cell table, and the histogram fits next to the table
@@ -1703,7 +1777,7 @@ hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipSt
       args.cells = nullptr;
     }
     if (counted) *counted = counts;
-    if (static_launch_aggregate(args, grid, AGG_WIDE_THREADS, lds, stream, &werr, kernel_name, spill_kernel)) return werr;
+    if (static_launch_aggregate(args, grid, AGG_WIDE_THREADS, lds, stream, &werr, kernel_name, spill_kernel ? 1 : 0)) return werr;
     if (spill_kernel) {
       if (jit_launch(JIT_AGGREGATE_SPILL, spec_fields_spill(args), &args, dev.jit, dev.device, grid, AGG_WIDE_THREADS, lds, stream, &werr, kernel_name)) return werr;
     } else if (jit_launch(JIT_AGGREGATE, spec_fields(args), &args, dev.jit, dev.device, grid, AGG_WIDE_THREADS, lds, stream, &werr, kernel_name)) {
@@ -1803,7 +1877,8 @@ bool spill_onepass_available(int bits, uint32_t n_inputs) {
   return on != 2 && bits <= 9 && (1 << bits) <= ONEPASS_MAX_PARTS && n_inputs <= 1;
 }
 
-hipError_t launch_spill_scatter_onepass(const AggSpill &sp, int n_segments, int bits, int blocks, const int32_t *dst_cells, void *dst_rows, hipStream_t stream) {
+hipError_t launch_spill_scatter_onepass(const AggSpill &sp, int n_segments, int bits, int blocks, const int32_t *dst_cells, int cells_stride, void *dst_rows,
+                                        hipStream_t stream) {
   if (!spill_onepass_available(bits, sp.n_inputs)) return hipErrorInvalidValue;
   OnePassArgs a{};
   a.sp = sp;
@@ -1812,6 +1887,7 @@ hipError_t launch_spill_scatter_onepass(const AggSpill &sp, int n_segments, int 
   a.dst_cells = dst_cells;
   a.dst = (KeyVal *)dst_rows;
   a.n_inputs = sp.n_inputs;
+  a.cells_stride = (uint32_t)(cells_stride > 0 ? cells_stride : blocks);
   const size_t P = (size_t)1 << bits;
   const size_t lds = P * ONEPASS_RING * sizeof(KeyVal) + P * (3 * sizeof(uint32_t) + sizeof(unsigned long long)) + 2 * P * sizeof(uint32_t);
   static bool attr_set = false;
@@ -1835,7 +1911,8 @@ hipError_t launch_aggregate_partitioned(const PartArgs &args, const DeviceInfo &
   size_t lds = agg_lds_bytes(args.n_accs, args.lds_cap, false);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)qe_aggregate_partitioned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    // (the table takes at most 148 KiB - partitioned_lds_slots - and the kernel's static arrays 8 KiB of the unit's 160)
+    hipError_t e = hipFuncSetAttribute((const void *)qe_aggregate_partitioned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }

@@ -136,5 +136,11 @@ inline SpecFields spec_fields_spill(const AggArgs &A) {
   f.sig.push_back(0x5104u);
   return f;
 }
+// ... and as the first pass that partitions its rows itself.
+inline SpecFields spec_fields_direct(const AggArgs &A) {
+  SpecFields f = spec_fields(A);
+  f.sig.push_back(0xD12Eu);
+  return f;
+}
 
 }  // namespace qe

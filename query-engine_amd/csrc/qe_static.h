@@ -918,6 +918,7 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_spill_static
   SpillState sp = spill_begin(A.spill, wave);
   const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
   uint32_t turn = wave >> 2;  // (waves 4 apart share a SIMD)
+  uint32_t selected = 0;      // rows of this wave that passed the predicate with a valid key (wave-uniform)
   for (int64_t ws = (int64_t)blockIdx.x * n_waves + wave; ws < nsteps; ws += (int64_t)gridDim.x * n_waves) {
     if (A.tune & 8u) {
       // The four waves of a SIMD take the high priority in turn, a step each.  Left alone the oldest wave is served
@@ -947,18 +948,229 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_spill_static
     for (int j = 0; j < VM_R; ++j) G.off[j] = 0;
     Slot in[Spec::n_accs > 0 && Spec::n_accs <= SPILL_ROW_MAJOR_ACCS ? Spec::n_accs : 1];
     spill_tasks_static<Spec, 0>(A, L, c, K, G, in, sp, hist);
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) selected += (uint32_t)__popcll(__ballot((((G.hit | G.miss) >> j) & 1u) != 0));
   }
   spill_end(A.spill, sp, wave, lane);
   if (hist) {
     // this workgroup's column of the partition passes' cell table, and its share of the log's length
     __syncthreads();
-    for (uint32_t p = threadIdx.x; p < (1u << A.cell_bits); p += blockDim.x) A.cells[(size_t)p * gridDim.x + blockIdx.x] = (int32_t)hist[p];
+    const uint32_t cells_stride = A.cells_stride ? A.cells_stride : gridDim.x;
+    for (uint32_t p = threadIdx.x; p < (1u << A.cell_bits); p += blockDim.x) A.cells[(size_t)p * cells_stride + blockIdx.x] = (int32_t)hist[p];
 #ifdef QE_ABLATE
     if (A.tune & 0x150u) sp.cursor = 0;  // (the log is not what the histogram says: the partition passes see none)
 #endif
     if (lane == 0 && sp.cursor != 0) atomicAdd(A.cells_total, (unsigned long long)sp.cursor);
+    // (a launch with a block of columns in a shared cell table also says how many rows it saw: logged / selected is what
+    // the host chooses between this kernel and the one that partitions directly by)
+    if (lane == 0 && selected != 0 && A.cells_stride != 0) atomicAdd(A.cells_total + 2, (unsigned long long)selected);
   }
-  if (!(A.tune & 4u)) agg_flush(L, A.table, A.accs, Spec::n_accs);  // (bit 2: timing experiments)
+  if (!(A.tune & 4u)) agg_flush(L, A.table, A.accs, Spec::n_accs);  // (bit 2: a launch whose results are thrown away - the host's look at how many rows miss the tables)
+}
+
+
+// ------------------------------------------------- first pass of the many-groups mode that partitions as it goes
+// When nearly every selected row misses the workgroup's table (very many keys, none of them frequent) the table is of
+// no use, and logging the rows only to read them back and partition them costs a write and a read of every one.  This
+// first pass has no table and no log: a workgroup evaluates predicate, key and value, and collects each partition's
+// rows as (key, value) pairs in a ring of 16 rows - two 128-byte lines - in LDS (512 partitions x 256 bytes), writing
+// a line the moment its eight rows are there.  No count pass comes first, so a workgroup cannot know where its rows of
+// a partition will lie among everybody's: each (partition, workgroup) has a stretch of its own, sized for its expected
+// share with room to spare, and the partition-wise aggregate walks a partition's stretches.  A stretch that turns out
+// too small drops the rows beyond it and says so (AggSpill::counts[0]): the caller then runs the batch through the
+// table-and-log first pass instead - skewed keys, for which that one is the right choice anyway.
+// The waves of a workgroup move in rounds (a barrier between the rows' arrival and the writing of complete lines), so
+// a wave's next step's columns are fetched before it works on the current one: nobody else is there to hide that trip.
+
+template <class Spec, int T>
+__device__ __forceinline__ void direct_tasks_static(const AggArgs &A, RowCtx &c, const ColCache &K, uint64_t (&key)[VM_R], uint64_t (&val)[VM_R]) {
+  if constexpr (T < Spec::n_tasks) {
+    constexpr uint32_t role = Spec::task_role[T], idx = Spec::task_idx[T];
+    if constexpr (role == ROLE_LOOKUP) {
+      if (__ballot(c.active != 0) == 0) return;
+    } else if constexpr (role == ROLE_ACC) {
+      if (A.spill_col[idx] != 0xffu) {  // (uniform: the accumulator whose input is the row's value)
+        Slot S[VM_MAX_DEPTH];
+        S[0].valid = 0xFu;
+#pragma unroll
+        for (int j = 0; j < VM_R; ++j) S[0].v[j] = 1;
+        if constexpr (Spec::task_eval[T] != 0) eval_static<Spec, Spec::task_pc[T]>(A.prog, c, K, S);
+#pragma unroll
+        for (int j = 0; j < VM_R; ++j) val[j] = S[0].v[j];
+      }
+    } else {
+      Slot S[VM_MAX_DEPTH];
+      S[0].valid = 0xFu;
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) S[0].v[j] = 1;
+      if constexpr (Spec::task_eval[T] != 0) eval_static<Spec, Spec::task_pc[T]>(A.prog, c, K, S);
+      if constexpr (role == ROLE_PRED) {
+        c.active &= S[0].valid & bool_bits(S[0]);
+        if (__ballot(c.active != 0) == 0) return;  // nothing of this wave-step survives the filter
+      } else {
+        c.active &= S[0].valid;
+        constexpr uint32_t kbits = Spec::key_bits[idx], sh = Spec::key_shift[idx];
+        constexpr uint64_t fmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
+#pragma unroll
+        for (int j = 0; j < VM_R; ++j) key[j] |= (S[0].v[j] & fmask) << sh;
+      }
+    }
+    direct_tasks_static<Spec, T + 1>(A, c, K, key, val);
+  }
+}
+
+template <class Spec>
+__global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_direct_static(const AggArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lds_raw[];
+  const uint32_t P = 1u << A.cell_bits;
+  // A ring's stride is 17 rows: with 16 (256 bytes) every partition's slot i would sit in the same LDS banks.
+  KeyVal *ring = (KeyVal *)lds_raw;                                              // [P][DIRECT_RING_STRIDE]
+  unsigned long long *s_state = (unsigned long long *)(ring + (size_t)P * DIRECT_RING_STRIDE);  // [P] low word: rows arrived; high word: first row not yet written (a multiple of 8)
+  uint32_t *s_valid = (uint32_t *)(s_state + P);                                 // [P] bit i: ring slot i holds a row
+  uint32_t *s_ready = s_valid + P;                                               // [2 P] lines to write this round: partition | line number << 9
+  uint32_t *s_nready = s_ready + 2 * P;                                          // [2] their number, rounds taking turns
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  const int64_t n = A.n_rows;
+  const uint32_t cap = A.spill.direct_cap;
+  KeyVal *dst = (KeyVal *)A.spill.keys;
+  auto stretch = [&](uint32_t p) { return ((uint64_t)p * gridDim.x + blockIdx.x) * cap; };
+
+  for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
+    s_state[p] = 0;
+    s_valid[p] = 0;
+  }
+  if (threadIdx.x < 2) s_nready[threadIdx.x] = 0;
+  lds_barrier();
+
+  // Writes the lines that are complete (every row of them has arrived); `all`: whatever has arrived, at the end.
+  // Three barriers a round: after the rows' arrival, after the list of lines, after the writing.
+  uint32_t turn = 0;
+  auto flush = [&](bool all) {
+    uint32_t *nready_at = s_nready + (turn & 1u);
+    for (uint32_t t = threadIdx.x; t < 2 * P; t += blockDim.x) {  // (2 P is a multiple of 64: a wave's lanes stay together)
+      const uint32_t p = t >> 1, j = t & 1u;
+      const unsigned long long st = s_state[p];
+      const uint32_t uw = (uint32_t)st, line0 = (uint32_t)(st >> 32) + 8u * j;  // rows [line0, line0 + 8)
+      const bool ready = uw >= line0 + 8u || (all && uw > line0);
+      const uint64_t m = __ballot(ready);
+      if (m != 0) {  // (one atomic a wave)
+        uint32_t at = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) at = atomicAdd(nready_at, (uint32_t)__popcll(m));
+        at = (uint32_t)__builtin_amdgcn_readlane((int)at, __builtin_ctzll(m));
+        if (ready) s_ready[at + mbcnt64(m)] = p | ((line0 >> 3) << 9);
+      }
+    }
+    lds_barrier();
+    const uint32_t nready = *nready_at;
+    if (threadIdx.x == 0) s_nready[(turn + 1u) & 1u] = 0;  // (last read before the barrier that ended the previous round)
+    for (uint32_t q = wave * 8u; q < nready; q += n_waves * 8u) {
+      const uint32_t e = q + (lane >> 3);
+      if (e < nready) {
+        const uint32_t entry = s_ready[e], p = entry & 511u, line = entry >> 9, r = lane & 7u;
+        const uint32_t slot = (line & 1u) * 8u + r;
+#ifdef QE_ABLATE  // timing experiments (results are wrong): 0x400 = the lines are not written to memory
+        if (A.tune & 0x400u) {
+          if (ring[(size_t)p * DIRECT_RING_STRIDE + slot].key == 0x123456789ull) dst[0].key = 0;
+        } else
+#endif
+        if ((s_valid[p] >> slot) & 1u) {
+          const KeyVal row = ring[(size_t)p * DIRECT_RING_STRIDE + slot];
+          qe_ull2 t;
+          t.x = row.key;
+          t.y = row.val;
+          if (A.tune & 0x10u) __builtin_nontemporal_store(t, (qe_ull2 *)&dst[stretch(p) + line * 8u + r]);
+          else dst[stretch(p) + line * 8u + r] = row;
+        }
+        // the written line leaves the window (a partition's two lines are listed in order, and both or the first)
+        if (r == 0) {
+          atomicAnd(&s_valid[p], ~(0xffu << (8u * (line & 1u))));
+          atomicAdd(&s_state[p], 8ull << 32);
+        }
+      }
+    }
+    lds_barrier();
+    ++turn;
+  };
+
+  const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
+  const int64_t steps_a_round = (int64_t)gridDim.x * n_waves;
+  const int64_t rounds = (nsteps + steps_a_round - 1) / steps_a_round;  // the same for every wave: barriers inside
+  auto fetch = [&](int64_t ws, RowCtx &c, ColCache &K) __attribute__((always_inline)) {
+    c.row0 = ws * VM_WAVE_ROWS;
+    c.n = n;
+    c.lane = lane;
+    c.active = in_range_bits(c.row0, lane, n);  // (nothing beyond the last step)
+    cache_fill_static<Spec, (1u << Spec::cache_n) - 1u, 0>(A.prog, c, K);
+  };
+  int64_t ws = (int64_t)blockIdx.x * n_waves + wave;
+  RowCtx cn;
+  ColCache Kn;
+  fetch(ws, cn, Kn);
+  uint32_t dropped = 0;
+  for (int64_t r = 0; r < rounds; ++r) {
+    RowCtx c;
+    c.row0 = cn.row0;
+    c.n = n;
+    c.lane = lane;
+    c.active = cn.active;
+    ColCache K;
+    cache_copy_static<Spec, (1u << Spec::cache_n) - 1u, 0>(K, Kn);
+    ws += steps_a_round;
+    fetch(ws, cn, Kn);  // a round ahead: the trip to memory overlaps this round's work and barriers
+    uint64_t key[VM_R], val[VM_R];
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) key[j] = 0, val[j] = 0;
+    direct_tasks_static<Spec, 0>(A, c, K, key, val);
+#ifdef QE_ABLATE  // 0x800 = the rows go nowhere and the waves do not wait for each other; 0x200 = the rows go nowhere, the rounds stay
+    if (A.tune & 0x800u) continue;
+    if (A.tune & 0x200u) c.active = 0;
+#endif
+    // the rows take their places: one LDS operation numbers a row and tells it where the ring's window starts
+    uint32_t part[VM_R];
+    unsigned long long st[VM_R];
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) {
+      part[j] = partition_of(key[j], A.cell_bits);
+      st[j] = 0;
+      if ((c.active >> j) & 1u) st[j] = atomicAdd(&s_state[part[j]], 1ull);
+    }
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) {
+      if ((c.active >> j) & 1u) {
+        const uint32_t u = (uint32_t)st[j], ur = (uint32_t)(st[j] >> 32);
+        KeyVal row;
+        row.key = key[j];
+        row.val = val[j];
+        if (u >= cap) {
+          dropped = 1;  // the stretch is full
+        } else if (u < ur + (uint32_t)DIRECT_RING) {
+          ring[(size_t)part[j] * DIRECT_RING_STRIDE + (u & (DIRECT_RING - 1))] = row;
+          atomicOr(&s_valid[part[j]], 1u << (u & (DIRECT_RING - 1)));
+        } else {
+          dst[stretch(part[j]) + u] = row;  // the ring is full: straight to its place (the line is completed around it)
+        }
+      }
+    }
+    lds_barrier();
+    flush(false);
+  }
+  flush(true);
+  // what this workgroup wrote, per partition
+  const uint32_t cells_stride = A.cells_stride ? A.cells_stride : gridDim.x;
+  uint32_t mine = 0;
+  for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
+    uint32_t got = (uint32_t)s_state[p];
+#ifdef QE_ABLATE
+    if (A.tune & 0xe00u) got = 0;  // (what was written is not what the counts would say: the partition pass sees nothing)
+#endif
+    if (got > cap) dropped = 1;
+    A.cells[(size_t)p * cells_stride + blockIdx.x] = (int32_t)(got < cap ? got : cap);
+    mine += got < cap ? got : cap;
+  }
+  if (__ballot(dropped != 0) != 0 && lane == 0) atomicOr(A.spill.counts, 1u);
+  // (the total of the rows written: sizes nothing, but says how selective the batch was)
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+  if (lane == 0 && mine != 0) atomicAdd(A.cells_total, (unsigned long long)mine);
 }
 
 }  // namespace qe

@@ -22,6 +22,8 @@ struct Entry {
   void (*aggregate)(const AggArgs &, int, int, size_t, hipStream_t);
   void (*aggregate_spill)(const AggArgs &, int, int, size_t, hipStream_t);  // the high-cardinality mode's first pass
   const char *(*spill_name)();
+  void (*aggregate_direct)(const AggArgs &, int, int, size_t, hipStream_t);  // ... the one that partitions its rows itself
+  const char *(*direct_name)();
 };
 
 template <class Spec>
@@ -70,13 +72,30 @@ const char *spill_kernel_name() {
   return name.c_str();
 }
 
-#define QE_ENTRY_PROJECT(S) Entry{S::name, S::sig, S::n_sig, run_project<S>, nullptr, nullptr, nullptr, nullptr},
-#define QE_ENTRY_FILTER(S) Entry{S::name, S::sig, S::n_sig, nullptr, run_filter<S>, nullptr, nullptr, nullptr},
-#define QE_ENTRY_AGGREGATE(S) Entry{S::name, S::sig, S::n_sig, nullptr, nullptr, run_aggregate<S>, run_aggregate_spill<S>, spill_kernel_name<S>},
+template <class Spec>
+void run_aggregate_direct(const AggArgs &a, int grid, int block_threads, size_t lds, hipStream_t s) {
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute((const void *)qe_aggregate_direct_static<Spec>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    raised = true;
+  }
+  hipLaunchKernelGGL(qe_aggregate_direct_static<Spec>, dim3(grid), dim3(block_threads), lds, s, a);
+}
+template <class Spec>
+const char *direct_kernel_name() {
+  static const std::string name = std::string("qe_aggregate_direct") + (Spec::name + std::strlen("qe_aggregate"));
+  return name.c_str();
+}
+
+#define QE_ENTRY_PROJECT(S) Entry{S::name, S::sig, S::n_sig, run_project<S>, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
+#define QE_ENTRY_FILTER(S) Entry{S::name, S::sig, S::n_sig, nullptr, run_filter<S>, nullptr, nullptr, nullptr, nullptr, nullptr},
+#define QE_ENTRY_AGGREGATE(S) \
+  Entry{S::name, S::sig, S::n_sig, nullptr, nullptr, run_aggregate<S>, run_aggregate_spill<S>, spill_kernel_name<S>, run_aggregate_direct<S>, direct_kernel_name<S>},
 
 const Entry g_entries[] = {
     QE_STATIC_PROJECT_SPECS(QE_ENTRY_PROJECT) QE_STATIC_FILTER_SPECS(QE_ENTRY_FILTER)
-        QE_STATIC_AGGREGATE_SPECS(QE_ENTRY_AGGREGATE) Entry{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr}};
+        QE_STATIC_AGGREGATE_SPECS(QE_ENTRY_AGGREGATE) Entry{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
 
 const Entry *find(const std::vector<uint32_t> &sig) {
   for (const Entry *e = g_entries; e->name; ++e)
@@ -110,13 +129,14 @@ bool static_has_aggregate(const AggArgs &args) {
 }
 
 bool static_launch_aggregate(const AggArgs &args, int grid, int block_threads, size_t lds_bytes, hipStream_t stream, hipError_t *err,
-                             const char **kernel_name, bool spill_first_pass) {
+                             const char **kernel_name, int first_pass) {
   const Entry *e = find(signature(args));
   if (!e || !e->aggregate) return false;
-  if (spill_first_pass) e->aggregate_spill(args, grid, block_threads, lds_bytes, stream);
+  if (first_pass == 2) e->aggregate_direct(args, grid, block_threads, lds_bytes, stream);
+  else if (first_pass == 1) e->aggregate_spill(args, grid, block_threads, lds_bytes, stream);
   else e->aggregate(args, grid, block_threads, lds_bytes, stream);
   *err = hipGetLastError();
-  if (kernel_name) *kernel_name = spill_first_pass ? e->spill_name() : e->name;
+  if (kernel_name) *kernel_name = first_pass == 2 ? e->direct_name() : first_pass == 1 ? e->spill_name() : e->name;
   return true;
 }
 

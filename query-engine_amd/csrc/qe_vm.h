@@ -225,6 +225,13 @@ struct AggSpill {
   // 1: a log with one value column holds (key, value) pairs of 16 bytes in `keys` (row i at keys[2 i], keys[2 i + 1];
   // `vals` is not used): the first pass writes a row with one 16-byte store, the scatter reads it with one load.
   uint32_t pairs;
+  // Not 0: no log at all - the first pass partitions its rows itself (qe_aggregate_direct_static).  `keys` then holds
+  // pairs in one stretch of `direct_cap` rows (a multiple of 8) per partition and workgroup, stretch (p, b) at row
+  // (p * workgroups + b) * direct_cap; AggArgs::cells[p * cells_stride + b] receives the rows written there and
+  // counts[0] is set when some stretch was too small for its rows (which are then missing: the caller runs the batch
+  // again, through the log).
+  uint32_t direct_cap;
+  uint32_t direct_pad;
 };
 
 struct AggArgs {
@@ -251,8 +258,11 @@ struct AggArgs {
   unsigned long long *cells_total;
   int32_t cell_bits;
   uint32_t hist_off;
-  uint32_t tune;                   // bit 0: no hot keys in registers for this launch; bit 1 (host): the caller promised many groups
-  uint32_t tune_pad;
+  uint32_t tune;                   // bit 0: no hot keys in registers for this launch; bit 1 (host): the caller promised many groups;
+                                   // bit 2: the many-groups first pass leaves its tables unflushed (a trial launch); bit 3: its waves take the high priority in turn
+  // Columns in a row of the cell table (0 = the launch's workgroups).  Several launches whose logs are partitioned
+  // together share one table, each with a block of columns of its own: `cells` then points at this launch's first.
+  uint32_t cells_stride;
 };
 
 // Does the workgroup's LDS table keep per-accumulator counts of valid inputs?  Host and device size the table alike.
@@ -261,6 +271,25 @@ inline __host__ __device__ bool agg_tracks_validity(const VmAcc *accs, int n_acc
     if (accs[a].track_nn) return true;
   return false;
 }
+
+// The first pass that partitions its rows itself: rows a partition's ring in LDS holds (two 128-byte lines of eight
+// pairs), the most partitions it serves, and the LDS a workgroup takes (rings, three words a partition, the list of
+// lines to write).
+constexpr int DIRECT_RING = 16;
+constexpr int DIRECT_RING_STRIDE = 17;  // rows from one ring to the next
+constexpr int DIRECT_MAX_PARTS = 512;
+constexpr size_t direct_lds_bytes(int bits) { return ((size_t)1 << bits) * (DIRECT_RING_STRIDE * 16 + 8 + 4 + 2 * 4) + 64; }
+
+// Rows a first pass partitioned itself (AggSpill::direct_cap): stretch (p, b) of `cap` pairs at rows[(p * blocks + b) * cap],
+// counts[p * counts_stride + b] of them filled.
+struct PartDirect {
+  const unsigned long long *rows;
+  const int32_t *counts;
+  uint32_t cap;
+  uint32_t counts_stride;
+};
+constexpr int PART_MAX_DIRECT = 8;         // such sources per launch of the partition-wise aggregate
+constexpr int PART_MAX_DIRECT_UNITS = 2048;  // ... and stretches per partition over all of them
 
 // Second phase of the high-cardinality mode: the spilled rows, partitioned by key hash.
 struct PartArgs {
@@ -281,6 +310,10 @@ struct PartArgs {
   unsigned long long *ticket;      // zeroed before the launch
   int32_t ablate;                  // timing experiments only (QE_PART_ABLATE): 1 no flush, 2 no fold, 4 no lookup
   int32_t interleaved;             // 1: `keys` holds (key, value) pairs of 16 bytes, one value column (the one-pass scatter's output)
+  // On top of (or, with keys == nullptr, instead of) the partitioned copy: rows that first passes partitioned themselves.
+  int32_t n_direct;
+  int32_t direct_blocks;           // workgroups of those first passes = stretches per partition and source
+  PartDirect direct[PART_MAX_DIRECT];
 };
 
 constexpr int FIX_FRACTION_BITS = 96;  // fixed-point digits below 2^S

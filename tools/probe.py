@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small single-GPU driver for profiling one configuration under rocprofv3.
 
-usage: probe.py <c2|c3|c5|c4|c5m|p|utf8> [rows] [reps]   (c5m: the c5 plan over 1 M uniform keys; utf8: the reference's
+usage: probe.py <c2|c3|c5|c4|c5m|p|utf8> [rows] [reps] [batches]   (the rows in that many equal batches, default 1; c5m: the c5 plan over 1 M uniform keys; utf8: the reference's
 test_filter shape at 100 M rows, bench.py's utf8_filter_config, with the deferred row count)
 """
 import importlib
@@ -20,6 +20,7 @@ def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else "c5"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 64_000_000
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    n_batches = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     ctx = qe.Context(0, stream=torch.cuda.current_stream().cuda_stream)
@@ -45,10 +46,11 @@ def main():
     ctx.generate(0, 46, 0, n, 0.0, 1.0, c.data_ptr())
     ctx.synchronize()
     C = qe.ColumnExpression
-    batch = qe.Batch.from_torch(ctx, [k, a, b, c])
+    per = (n + n_batches - 1) // n_batches
+    batches = [qe.Batch.from_torch(ctx, [t[i:i + per] for t in (k, a, b, c)]) for i in range(0, n, per)]
 
     def plan():
-        scan = qe.ScanExec(ctx, [batch])
+        scan = qe.ScanExec(ctx, batches)
         if cfg == "c2":
             sel = qe.SelectionExec([scan], qe.GtExpression(C(3), qe.LiteralFloatExpression(0.5)))
             return qe.ProjectionExec([sel], [qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
@@ -68,7 +70,7 @@ def main():
         try:
             return list(plan().execute())[0]
         except qe.QeError:
-            if "QE_SPILL_ABLATE_FIRST" not in os.environ:  # (a library built for timing experiments may leave nothing to return)
+            if "QE_SPILL_ABLATE_FIRST" not in os.environ and "QE_DIRECT_ABLATE" not in os.environ:  # (a library built for timing experiments may leave nothing to return)
                 raise
 
             class Nothing:
