@@ -1202,13 +1202,12 @@ __device__ __forceinline__ uint32_t lds_pair_find_or_claim4(const LdsTable &L, c
     uint64_t k0[VM_R], k1[VM_R];
 #pragma unroll
     for (int j = 0; j < VM_R; ++j) {
-      k0[j] = k1[j] = 0;
-      if ((open >> j) & 1u) {
-        // (b is even and the key array 16-byte aligned: one 16-byte read)
-        const U64x2 two = *(const U64x2 *)__builtin_assume_aligned(&L.keys[b[j]], 16);
-        k0[j] = two.x;
-        k1[j] = two.y;
-      }
+      // (b is even and the key array 16-byte aligned: one 16-byte read.  Every row reads - a row that is not open the
+      // table's first bucket, one address for all such lanes, which costs the LDS next to nothing: behind a test of its
+      // lane mask each read would be waited for before the next one is issued, four LDS round trips a round instead of one)
+      const U64x2 two = *(const U64x2 *)__builtin_assume_aligned(&L.keys[((open >> j) & 1u) ? b[j] : 0u], 16);
+      k0[j] = two.x;
+      k1[j] = two.y;
     }
     uint32_t want = 0;  // rows whose probe ended at an empty slot without finding the key
 #pragma unroll
@@ -1257,6 +1256,99 @@ __device__ __forceinline__ uint32_t lds_pair_find_or_claim4(const LdsTable &L, c
           b[j] = again ? (b[j] & ~1u) : b[j];
         }
       }
+    }
+  }
+  return hit;
+}
+
+// The lookup of the partition-wise aggregate, where every key must find a slot: the home buckets of a lane's four rows
+// are read together (one LDS round trip), and whatever that look has not settled - a key further down its probe
+// sequence, a new key that claims an empty slot - goes on ONE row per lane at a time.  An LDS instruction costs the
+// unit its dozen cycles whatever the number of lanes that want something, and after the first look few lanes do: four
+// instructions a round for the stragglers (lds_pair_find_or_claim4) were half the partition pass's LDS time.
+// Returns the rows that have a slot (slot8[j] = slot x 8); a row is left out when the table has reached its limit
+// or `rounds` looks per row were not enough (the caller has another home for it).
+__device__ __forceinline__ uint32_t lds_pair_find_or_claim_rows(const LdsTable &L, const uint64_t (&key)[VM_R], uint32_t rows, int rounds,
+                                                                uint32_t (&slot8)[VM_R]) {
+  const uint32_t mask = L.cap - 1;
+  uint32_t b[VM_R];
+  uint32_t todo = rows, hit = 0;
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j) {
+    b[j] = hash32(key[j]) & mask & ~1u;
+    slot8[j] = 0;
+  }
+  {
+    // the one key equal to the empty marker lives in the reserved slot
+    uint32_t marker = 0;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) marker |= (((rows >> j) & 1u) && key[j] == AGG_EMPTY_KEY) ? 1u << j : 0u;
+    if (__ballot(marker != 0) != 0) {
+      if (marker != 0) (void)atomicCAS(&L.keys[L.cap], AGG_EMPTY_KEY, 0ull);
+#pragma unroll
+      for (int j = 0; j < VM_R; ++j) slot8[j] = ((marker >> j) & 1u) ? L.cap * 8u : slot8[j];
+      hit |= marker;
+      todo &= ~marker;
+    }
+  }
+  {
+    // the first look (a row that is not looked for reads the table's first bucket: one address for all such lanes)
+    uint64_t k0[VM_R], k1[VM_R];
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) {
+      const U64x2 two = *(const U64x2 *)__builtin_assume_aligned(&L.keys[((todo >> j) & 1u) ? b[j] : 0u], 16);
+      k0[j] = two.x;
+      k1[j] = two.y;
+    }
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) {
+      const bool o = ((todo >> j) & 1u) != 0;
+      const bool h0 = o && k0[j] == key[j], h1 = o && k1[j] == key[j];
+      const bool found = h0 || h1;
+      const bool has_empty = k0[j] == AGG_EMPTY_KEY || k1[j] == AGG_EMPTY_KEY;
+      slot8[j] = found ? (b[j] + (h0 ? 0u : 1u)) * 8u : slot8[j];
+      hit |= found ? 1u << j : 0u;
+      todo &= found ? ~(1u << j) : ~0u;
+      b[j] = (o && !found && !has_empty) ? ((b[j] + 2u) & mask) : b[j];  // (a bucket with an empty slot is looked at again below, to claim it)
+    }
+  }
+  // the stragglers, one row per lane and look
+#pragma unroll 1
+  for (int r = 0; r < rounds * VM_R; ++r) {
+    if (__ballot(todo != 0) == 0) break;
+    const bool any = todo != 0;
+    const uint32_t jj = any ? (uint32_t)__builtin_ctz(todo) : 0u;
+    uint64_t kk = opaque64(key[3]);
+    uint32_t bb = opaque(b[3]);
+    if (jj == 2u) kk = opaque64(key[2]), bb = opaque(b[2]);
+    if (jj == 1u) kk = opaque64(key[1]), bb = opaque(b[1]);
+    if (jj == 0u) kk = opaque64(key[0]), bb = opaque(b[0]);
+    const U64x2 two = *(const U64x2 *)__builtin_assume_aligned(&L.keys[any ? bb : 0u], 16);
+    const bool h0 = any && two.x == kk, h1 = any && two.y == kk;
+    const bool e0 = two.x == AGG_EMPTY_KEY, e1 = two.y == AGG_EMPTY_KEY;
+    bool found = h0 || h1, gone = false;
+    uint32_t at = bb + (h0 ? 0u : 1u);
+    if (any && !found && (e0 || e1)) {
+      // a new key: the bucket's first empty slot, if the table still takes keys
+      at = bb + (e0 ? 0u : 1u);
+      if (*(volatile uint32_t *)L.used < L.limit) {
+        const unsigned long long old = atomicCAS(&L.keys[at], AGG_EMPTY_KEY, (unsigned long long)kk);
+        if (old == AGG_EMPTY_KEY) atomicAdd(L.used, 1u);
+        found = old == AGG_EMPTY_KEY || old == kk;  // (lost to another key: the same bucket once more - its other slot may be free)
+      } else {
+        gone = true;
+      }
+    } else if (any && !found) {
+      bb = (bb + 2u) & mask;
+    }
+    const uint32_t bit = any ? 1u << jj : 0u;
+    hit |= found ? bit : 0u;
+    todo &= (found || gone) ? ~bit : ~0u;
+#pragma unroll
+    for (int j = 0; j < VM_R; ++j) {
+      const bool me = any && jj == (uint32_t)j;
+      slot8[j] = (me && found) ? at * 8u : slot8[j];
+      b[j] = me ? bb : b[j];
     }
   }
   return hit;

@@ -484,6 +484,7 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_kernel(const Sc
 // finds its ring full is written straight to its place instead (a partial line, rare: rows arrive at half the rings'
 // capacity per round) and the line it belongs to is completed around it.  Only a cell's first and last line are partial.
 constexpr int ONEPASS_RING = 16;      // rows a partition's ring holds (two lines of eight)
+constexpr int ONEPASS_RING_STRIDE = 17;  // rows from one ring to the next
 constexpr int ONEPASS_ROWS = 2;       // rows per thread and round
 constexpr int ONEPASS_MAX_PARTS = 512;
 
@@ -500,59 +501,61 @@ struct OnePassArgs {
 __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_onepass_kernel(const OnePassArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long lds_stage[];
   const int P = 1 << A.bits;
-  KeyVal *ring = (KeyVal *)lds_stage;                                        // [P][ONEPASS_RING]
-  uint32_t *s_uw = (uint32_t *)(ring + (size_t)P * ONEPASS_RING);            // [P] rows arrived, counted from the line the cell starts in
-  uint32_t *s_ur = s_uw + P;                                                 // [P] first row not yet written (a multiple of 8)
-  uint32_t *s_valid = s_ur + P;                                              // [P] bit i: ring slot i holds a row
-  unsigned long long *s_dst0 = (unsigned long long *)(s_valid + P);          // [P] row index in dst of the ring's row 0 (cell start rounded down to a line)
-  uint32_t *s_ready = (uint32_t *)(s_dst0 + P);                              // [2 P] lines to write this round: partition << 1 | ring half
-  __shared__ uint32_t s_nready;
+  // (a ring's stride is 17 rows: with 16 - 256 bytes - every partition's slot i would sit in the same LDS banks)
+  KeyVal *ring = (KeyVal *)lds_stage;                                                        // [P][ONEPASS_RING_STRIDE]
+  unsigned long long *s_state = (unsigned long long *)(ring + (size_t)P * ONEPASS_RING_STRIDE);  // [P] low word: rows arrived, counted from the line the cell starts in; high word: first row not yet written (a multiple of 8)
+  unsigned long long *s_dst0 = s_state + P;                                                  // [P] row index in dst of the ring's row 0 (cell start rounded down to a line)
+  uint32_t *s_valid = (uint32_t *)(s_dst0 + P);                                              // [P] bit i: ring slot i holds a row
+  uint32_t *s_ready = s_valid + P;                                                           // [2 P] lines to write this round: partition | line number << 9
+  uint32_t *s_nready = s_ready + 2 * P;                                                      // [2] their number, rounds taking turns
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   auto BAR = [&]() { lds_barrier(); };
 
   for (int p = threadIdx.x; p < P; p += blockDim.x) {
     const uint64_t base = (uint64_t)(uint32_t)A.dst_cells[(size_t)p * A.cells_stride + blockIdx.x];
     s_dst0[p] = base & ~7ull;
-    s_uw[p] = (uint32_t)(base & 7ull);
-    s_ur[p] = 0;
+    s_state[p] = base & 7ull;
     s_valid[p] = 0;
   }
-  if (threadIdx.x == 0) s_nready = 0;
+  if (threadIdx.x < 2) s_nready[threadIdx.x] = 0;
   BAR();
 
   // Writes the lines that are complete (every row of them has arrived); `all`: whatever has arrived, at the end.
+  // Three barriers a round: after the rows' arrival, after the list of lines, after the writing.
+  uint32_t turn = 0;
   auto flush = [&](bool all) {
-    for (int t = threadIdx.x; t < 2 * P; t += blockDim.x) {
+    uint32_t *nready_at = s_nready + (turn & 1u);
+    for (int t = threadIdx.x; t < 2 * P; t += blockDim.x) {  // (2 P is a multiple of 64: a wave's lanes stay together)
       const uint32_t p = (uint32_t)t >> 1, j = (uint32_t)t & 1u;
-      const uint32_t line0 = s_ur[p] + 8u * j, uw = s_uw[p];  // rows [line0, line0 + 8)
-      if (uw >= line0 + 8u || (all && uw > line0)) s_ready[atomicAdd(&s_nready, 1u)] = (p << 1) | ((line0 >> 3) & 1u);
+      const unsigned long long st = s_state[p];
+      const uint32_t uw = (uint32_t)st, line0 = (uint32_t)(st >> 32) + 8u * j;  // rows [line0, line0 + 8)
+      const bool ready = uw >= line0 + 8u || (all && uw > line0);
+      const uint64_t m = __ballot(ready);
+      if (m != 0) {  // (one atomic a wave)
+        uint32_t at = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) at = atomicAdd(nready_at, (uint32_t)__popcll(m));
+        at = (uint32_t)__builtin_amdgcn_readlane((int)at, __builtin_ctzll(m));
+        if (ready) s_ready[at + mbcnt64(m)] = p | ((line0 >> 3) << 9);
+      }
     }
     BAR();
-    const uint32_t nready = s_nready;
+    const uint32_t nready = *nready_at;
+    if (threadIdx.x == 0) s_nready[(turn + 1u) & 1u] = 0;  // (last read before the barrier that ended the previous round)
     for (uint32_t q = wave * 8u; q < nready; q += n_waves * 8u) {
       const uint32_t e = q + (lane >> 3);
       if (e < nready) {
-        const uint32_t entry = s_ready[e], p = entry >> 1, half = entry & 1u, r = lane & 7u;
-        const uint32_t slot = half * 8u + r;
-        if ((s_valid[p] >> slot) & 1u) {
-          // the slot's row number: the ring's window starts at s_ur (a multiple of 8); this half is its first or second line
-          const uint32_t ur = s_ur[p];
-          const uint32_t u = ((ur >> 3) & 1u) == half ? ur + r : ur + 8u + r;
-          A.dst[s_dst0[p] + u] = ring[(size_t)p * ONEPASS_RING + slot];
+        const uint32_t entry = s_ready[e], p = entry & 511u, line = entry >> 9, r = lane & 7u;
+        const uint32_t slot = (line & 1u) * 8u + r;
+        if ((s_valid[p] >> slot) & 1u) A.dst[s_dst0[p] + line * 8u + r] = ring[(size_t)p * ONEPASS_RING_STRIDE + slot];
+        // the written line leaves the window (a partition's two lines are listed in order, and both or the first)
+        if (r == 0) {
+          atomicAnd(&s_valid[p], ~(0xffu << (8u * (line & 1u))));
+          atomicAdd(&s_state[p], 8ull << 32);
         }
       }
     }
     BAR();
-    // the written lines leave the window: two lines of one partition were both listed, the later one decides
-    for (uint32_t e = threadIdx.x; e < nready; e += blockDim.x) {
-      const uint32_t entry = s_ready[e], p = entry >> 1, half = entry & 1u;
-      const uint32_t ur = s_ur[p];
-      const uint32_t line_end = (((ur >> 3) & 1u) == half ? ur : ur + 8u) + 8u;
-      atomicMax(&s_ur[p], line_end);
-      atomicAnd(&s_valid[p], ~(0xffu << (8u * half)));
-    }
-    if (threadIdx.x == 0) s_nready = 0;
-    BAR();
+    ++turn;
   };
 
   struct Round {
@@ -611,16 +614,26 @@ __global__ __launch_bounds__(PART_THREADS) void qe_spill_scatter_onepass_kernel(
     Round nxt = cur;
     advance(nxt);
     fetch(nxt, nrow);  // a round ahead: the trip to memory overlaps this round's staging and barriers
+    // the rows take their places: one LDS operation numbers a row and tells it where the ring's window starts
+    uint32_t part[ONEPASS_ROWS];
+    unsigned long long st[ONEPASS_ROWS];
+    bool have[ONEPASS_ROWS];
 #pragma unroll
     for (int k = 0; k < ONEPASS_ROWS; ++k) {
-      if (cur.i0 + (uint32_t)k * blockDim.x + threadIdx.x < cur.cnt) {
-        const uint32_t p = partition_of(row[k].key, A.bits);
-        const uint32_t u = atomicAdd(&s_uw[p], 1u);
-        if (u < s_ur[p] + (uint32_t)ONEPASS_RING) {
-          ring[(size_t)p * ONEPASS_RING + (u & (ONEPASS_RING - 1))] = row[k];
-          atomicOr(&s_valid[p], 1u << (u & (ONEPASS_RING - 1)));
+      have[k] = cur.i0 + (uint32_t)k * blockDim.x + threadIdx.x < cur.cnt;
+      part[k] = partition_of(row[k].key, A.bits);
+      st[k] = 0;
+      if (have[k]) st[k] = atomicAdd(&s_state[part[k]], 1ull);
+    }
+#pragma unroll
+    for (int k = 0; k < ONEPASS_ROWS; ++k) {
+      if (have[k]) {
+        const uint32_t u = (uint32_t)st[k], ur = (uint32_t)(st[k] >> 32);
+        if (u < ur + (uint32_t)ONEPASS_RING) {
+          ring[(size_t)part[k] * ONEPASS_RING_STRIDE + (u & (ONEPASS_RING - 1))] = row[k];
+          atomicOr(&s_valid[part[k]], 1u << (u & (ONEPASS_RING - 1)));
         } else {
-          A.dst[s_dst0[p] + u] = row[k];  // the ring is full: straight to its place
+          A.dst[s_dst0[part[k]] + u] = row[k];  // the ring is full: straight to its place
         }
       }
     }
@@ -731,8 +744,19 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
     nxt.pos = nxt.end = 0;
     bool have = next_unit(nxt);
     if (have) fetch(nxt);
+#ifdef QE_ABLATE  // (bit 4: a wave's clock around the parts of a step, printed by one wave at the end)
+    unsigned long long t_wait = 0, t_look = 0, t_fold = 0, t_steps = 0, t_rounds = 0;
+#endif
     while (have) {
       if (table_given_up(A.table, watch)) break;
+#ifdef QE_ABLATE
+      unsigned long long c0 = 0;
+      if (A.ablate & 16) {
+        c0 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t_wait += __builtin_readcyclecounter() - c0;
+      }
+#endif
       AggRows G;
       Slot in;
       in.valid = 0xFu;
@@ -763,12 +787,25 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
           // a pair of slots a probe (one 16-byte LDS read): half the dependent round trips of the longest probe
           // sequence among the wave's 256 rows, which is what a step waits for
           uint32_t slot8[VM_R];
-          hit = lds_pair_find_or_claim4<false>(L, G.key, active, LDS_MAX_PROBE / 2, slot8);
+#ifdef QE_ABLATE
+          if (A.ablate & 16) c0 = __builtin_readcyclecounter();
+#endif
+          hit = lds_pair_find_or_claim_rows(L, G.key, active, LDS_MAX_PROBE / 2, slot8);
+#ifdef QE_ABLATE
+          if (A.ablate & 16) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            t_look += __builtin_readcyclecounter() - c0;
+            ++t_steps;
+          }
+#endif
 #pragma unroll
           for (int j = 0; j < VM_R; ++j) slot[j] = (int32_t)(slot8[j] >> 3);
         }
         if (__ballot(hit != active) == 0) {
           if (A.ablate & 2) continue;
+#ifdef QE_ABLATE
+          if (A.ablate & 16) c0 = __builtin_readcyclecounter();
+#endif
 #pragma unroll
           for (int j = 0; j < VM_R; ++j)
             if ((active >> j) & 1u) atomicAdd(&L.rowcnt[slot[j]], 1u);
@@ -800,6 +837,12 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
               }
             }
           }
+#ifdef QE_ABLATE
+          if (A.ablate & 16) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            t_fold += __builtin_readcyclecounter() - c0;
+          }
+#endif
           continue;
         }
       }
@@ -818,6 +861,12 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
           if (A.acc_col[a] == v) agg_fold(L, A.table, a, A.accs[a].op, A.accs[a].in_type, false, in, G, lane);
       }
     }
+#ifdef QE_ABLATE
+    if ((A.ablate & 16) && p == 7 && threadIdx.x == 128)
+      printf("partition 7 wave 2: %llu steps, cycles a step: wait for rows %llu, lookup %llu, fold %llu\n", t_steps, t_wait / (t_steps + 1), t_look / (t_steps + 1),
+             t_fold / (t_steps + 1));
+    (void)t_rounds;
+#endif
     if (!(A.ablate & 1)) agg_flush<true>(L, A.table, A.accs, A.n_accs);  // starts with a barrier
   }
 }
@@ -1889,10 +1938,10 @@ hipError_t launch_spill_scatter_onepass(const AggSpill &sp, int n_segments, int 
   a.n_inputs = sp.n_inputs;
   a.cells_stride = (uint32_t)(cells_stride > 0 ? cells_stride : blocks);
   const size_t P = (size_t)1 << bits;
-  const size_t lds = P * ONEPASS_RING * sizeof(KeyVal) + P * (3 * sizeof(uint32_t) + sizeof(unsigned long long)) + 2 * P * sizeof(uint32_t);
+  const size_t lds = P * ONEPASS_RING_STRIDE * sizeof(KeyVal) + P * (2 * sizeof(unsigned long long) + sizeof(uint32_t)) + 2 * P * sizeof(uint32_t) + 64;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)qe_spill_scatter_onepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void *)qe_spill_scatter_onepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
