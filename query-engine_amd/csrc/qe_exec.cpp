@@ -204,6 +204,14 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
       }
     }
     if (m <= 0) continue;
+    if (pending && utf8_gather_fused_available()) {
+      // the output bytes' buffers exist already: offsets and bytes in one pass (the tile that places its rows copies them)
+      ctx->prof_begin("qe_utf8_gather_fused_kernel");
+      QE_HIP(launch_utf8_gather_fused(launch, idx, m, m_dev, ctx->dev.cus, ctx->stream));
+      ctx->prof_end();
+      QE_HIP(hipMemcpyAsync(pending->host + 4 + CONTROL_WORDS * (first_slot + g0), scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+      continue;
+    }
     // lengths by row id, scanned into offsets, in one pass over all columns of the group; offs[m] = a column's byte total
     ctx->prof_begin("qe_utf8_gather_offsets_kernel");
     QE_HIP(launch_utf8_gather_offsets(launch, idx, m, m_dev, ctx->dev.cus, ctx->stream));

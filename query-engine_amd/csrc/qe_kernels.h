@@ -104,6 +104,10 @@ size_t utf8_gather_offsets_status_bytes(int64_t m);
 hipError_t launch_utf8_gather_offsets(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, const unsigned long long *m_dev, int cus, hipStream_t stream);
 // The bytes, once out_offsets are there and out_bytes has been sized from the totals.
 hipError_t launch_utf8_gather_bytes(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, const unsigned long long *m_dev, hipStream_t stream);
+// Offsets and bytes in one launch, for a caller that has set out_bytes before it knows the byte totals (buffers sized
+// by the sources): the tile that places its rows copies their bytes.  Same scratch as launch_utf8_gather_offsets.
+bool utf8_gather_fused_available();
+hipError_t launch_utf8_gather_fused(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, const unsigned long long *m_dev, int cus, hipStream_t stream);
 // Gather of strings by global row number over several source columns (group-by output keys).
 // Pass out_lengths to get the lengths (first pass), dst_offsets + dst_bytes to copy the bytes.
 struct Utf8Source {

@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(256) void qe_verify_group_keys_kernel(const VerifyA
 // handed out by a ticket counter, one status word a tile), validity bits gathered on the way.  scratch and status (a word per tile) start zeroed;
 // scratch->total receives the byte count, out_offsets[m] too.
 struct alignas(16) I32x4 { int32_t a, b, c, d; };
-constexpr int OFFSETS_THREADS = 1024, OFFSETS_TILE_MIN = 4096;  // (the status array is sized for the smallest tile)
+constexpr int OFFSETS_THREADS = 1024, OFFSETS_TILE_MIN = 2048;  // (the status array is sized for the smallest tile)
 template <int R>  // rows a lane, consecutive: 4, 8 or 16 (measured: 4 and 8 alike, 16 much slower)
 __global__ __launch_bounds__(OFFSETS_THREADS) void qe_utf8_gather_offsets_kernel(const Utf8GatherCols C, const int32_t *idx, int64_t m_bound,
                                                                                  const unsigned long long *m_dev) {
@@ -1369,7 +1369,86 @@ __device__ __forceinline__ uint32_t utf8_gather_dword(const int32_t *sd, const i
   return word;
 }
 
-// Every column of the launch, chunk by chunk.  (src_total, the bytes of the source column: a 16-byte fetch must end inside them.)
+// The bytes of one chunk - up to 64 consecutive output rows, a lane to a row - of one column.  sd[0..rows] are the rows'
+// output offsets (sd[rows]: where the chunk ends), ss[0..rows) their source offsets, both in LDS and written before the
+// call; `stage`: 64 * GATHER_SHORT + 16 bytes of LDS of the wave's own.  (src_total, the bytes of the source column: a
+// 16-byte fetch must end inside them.)
+__device__ __forceinline__ void utf8_copy_chunk(const uint8_t *__restrict__ src_bytes, int64_t src_total, uint8_t *__restrict__ dst_bytes, bool valid,
+                                                int32_t my_src, int32_t my_len, int32_t my_dst, const int32_t *sd, const int32_t *ss, uint8_t *stage,
+                                                int rows, uint32_t lane) {
+  const int32_t d0 = sd[0], d1 = sd[rows];
+  const int32_t a0 = d0 & ~3;  // the run's first dword
+  const bool in_bounds = (int64_t)my_src + ((my_len + 15) & ~15) <= src_total;  // (a 16-byte fetch of the row's last piece ends inside the source)
+  const bool is_short = my_len <= GATHER_SHORT && in_bounds;
+  // rows a lane cannot copy by itself: longer than 64 bytes (or at the very end of the source)
+  const uint64_t long_rows = __ballot(valid && !is_short);
+  if (long_rows == 0 || d1 - a0 <= (int32_t)(64 * GATHER_SHORT)) {
+    // ---- the run assembled in LDS: a lane fetches its own short row in pieces of 16 bytes; a row too long for that is
+    // fetched by the whole wave, a lane to a piece, the rare one (a chunk with one such row used to send all its 64 rows
+    // down the search path below: a column with 2 % long rows did so for 70 % of its chunks)
+    const uint32_t short_len = (valid && is_short) ? (uint32_t)my_len : 0u;
+    const int pieces = (__ballot(short_len > 0) != 0) + (__ballot(short_len > 16) != 0) + (__ballot(short_len > 32) != 0) + (__ballot(short_len > 48) != 0);
+    auto stage_piece = [&](const uint8_t *from, uint8_t *at, int32_t here) {  // `here` (1..16) bytes of a 16-byte fetch
+      uint32_t w[4];
+      __builtin_memcpy(w, from, 16);  // (any alignment: one 16-byte load)
+      // whole dwords as (unaligned) dword writes, the up to three bytes after them one by one: seven LDS
+      // instructions a piece at most, not sixteen
+      const int32_t full = here >> 2, tail = here & 3;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q < full) __builtin_memcpy(at + 4 * q, &w[q], 4);
+      if (tail) {
+        const uint32_t tw = full == 0 ? w[0] : full == 1 ? w[1] : full == 2 ? w[2] : w[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (t < tail) at[4 * full + t] = (uint8_t)(tw >> (8 * t));
+      }
+    };
+    for (int piece = 0; piece < pieces; ++piece) {
+      const int32_t left = (int32_t)short_len - 16 * piece;
+      if (left > 0) stage_piece(src_bytes + my_src + 16 * piece, stage + (my_dst - a0) + 16 * piece, left < 16 ? left : 16);
+    }
+    for (uint64_t rest = long_rows; rest != 0; rest &= rest - 1) {
+      const int q = __builtin_ctzll(rest);
+      const int32_t q_src = __builtin_amdgcn_readlane(my_src, q), q_dst = __builtin_amdgcn_readlane(my_dst, q), q_len = __builtin_amdgcn_readlane(my_len, q);
+      for (int32_t off = 16 * (int32_t)lane; off < q_len; off += 16 * 64) {
+        const int32_t left = q_len - off;
+        if ((int64_t)q_src + off + 16 <= src_total) {
+          stage_piece(src_bytes + q_src + off, stage + (q_dst - a0) + off, left < 16 ? left : 16);
+        } else {  // the source's last bytes: one at a time
+          for (int32_t b = 0; b < left && b < 16; ++b) stage[(q_dst - a0) + off + b] = src_bytes[q_src + off + b];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int32_t p4 = a0 + 4 * (int32_t)lane; p4 < d1; p4 += 256) {
+      const uint32_t word = *(const uint32_t *)(stage + (p4 - a0));
+      if (p4 >= d0 && p4 + 4 <= d1) {
+        *(uint32_t *)(dst_bytes + p4) = word;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (p4 + k >= d0 && p4 + k < d1) dst_bytes[p4 + k] = (uint8_t)(word >> (8 * k));
+      }
+    }
+  } else {
+    // ---- a run too long for the staging row: a lane takes four consecutive output bytes (one aligned dword store; the
+    // run's ragged ends go out byte by byte: the bytes next to them belong to other waves) and finds each byte's row
+    for (int32_t p4 = a0 + 4 * (int32_t)lane; p4 < d1; p4 += 256) {
+      const uint32_t word = utf8_gather_dword(sd, ss, rows, d0, d1, p4, src_bytes);
+      if (p4 >= d0 && p4 + 4 <= d1) {
+        *(uint32_t *)(dst_bytes + p4) = word;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (p4 + k >= d0 && p4 + k < d1) dst_bytes[p4 + k] = (uint8_t)(word >> (8 * k));
+      }
+    }
+  }
+}
+
+// Every column of the launch, chunk by chunk.
 __global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel(const Utf8GatherCols C, const int32_t *idx, int64_t m_bound,
                                                                                  const unsigned long long *m_dev) {
   const int64_t m = m_dev ? (int64_t)__hip_atomic_load(m_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : m_bound;
@@ -1393,94 +1472,168 @@ __global__ __launch_bounds__(GATHER_WAVES * 64) void qe_utf8_gather_bytes_kernel
     };
     fetch_offsets(0);
     for (int c = 0; c < C.n; ++c) {
-    const Utf8GatherCol &col = C.col[c];
-    const uint8_t *__restrict__ const src_bytes = col.src_bytes;
-    const int64_t src_total = col.src_total;
-    uint8_t *__restrict__ const dst_bytes = col.out_bytes;
-    int32_t my_src = 0, my_dst = 0, my_len = 0;
-    if (i < m) {
-      my_src = n_two[0];
-      my_len = n_two[1] - n_two[0];
-      my_dst = n_dst;
-      s_src[wave][lane] = my_src;
-      s_dst[wave][lane] = my_dst;
-    }
-    if (lane == 0) s_dst[wave][rows] = n_end;
-    fetch_offsets(c + 1);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's own LDS writes, before its reads below
-    __builtin_amdgcn_wave_barrier();
-    const int32_t *sd = s_dst[wave], *ss = s_src[wave];
-    const int32_t d0 = sd[0], d1 = sd[rows];
-    const int32_t a0 = d0 & ~3;  // the run's first dword
-    const bool in_bounds = (int64_t)my_src + ((my_len + 15) & ~15) <= src_total;  // (a 16-byte fetch of the row's last piece ends inside the source)
-    const bool is_short = my_len <= GATHER_SHORT && in_bounds;
-    // rows a lane cannot copy by itself: longer than 64 bytes (or at the very end of the source)
-    const uint64_t long_rows = __ballot(i < m && !is_short);
-    if (long_rows == 0 || d1 - a0 <= (int32_t)(64 * GATHER_SHORT)) {
-      // ---- the run assembled in LDS: a lane fetches its own short row in pieces of 16 bytes; a row too long for that is
-      // fetched by the whole wave, a lane to a piece, the rare one (a chunk with one such row used to send all its 64 rows
-      // down the search path below: a column with 2 % long rows did so for 70 % of its chunks)
-      const uint32_t short_len = is_short ? (uint32_t)my_len : 0u;
-      const int pieces = (__ballot(short_len > 0) != 0) + (__ballot(short_len > 16) != 0) + (__ballot(short_len > 32) != 0) + (__ballot(short_len > 48) != 0);
-      auto stage_piece = [&](const uint8_t *from, uint8_t *at, int32_t here) {  // `here` (1..16) bytes of a 16-byte fetch
-        uint32_t w[4];
-        __builtin_memcpy(w, from, 16);  // (any alignment: one 16-byte load)
-        // whole dwords as (unaligned) dword writes, the up to three bytes after them one by one: seven LDS
-        // instructions a piece at most, not sixteen
-        const int32_t full = here >> 2, tail = here & 3;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (q < full) __builtin_memcpy(at + 4 * q, &w[q], 4);
-        if (tail) {
-          const uint32_t tw = full == 0 ? w[0] : full == 1 ? w[1] : full == 2 ? w[2] : w[3];
-#pragma unroll
-          for (int t = 0; t < 3; ++t)
-            if (t < tail) at[4 * full + t] = (uint8_t)(tw >> (8 * t));
-        }
-      };
-      for (int piece = 0; piece < pieces; ++piece) {
-        const int32_t left = (int32_t)short_len - 16 * piece;
-        if (left > 0) stage_piece(src_bytes + my_src + 16 * piece, s_stage[wave] + (my_dst - a0) + 16 * piece, left < 16 ? left : 16);
+      const Utf8GatherCol &col = C.col[c];
+      int32_t my_src = 0, my_dst = 0, my_len = 0;
+      if (i < m) {
+        my_src = n_two[0];
+        my_len = n_two[1] - n_two[0];
+        my_dst = n_dst;
+        s_src[wave][lane] = my_src;
+        s_dst[wave][lane] = my_dst;
       }
-      for (uint64_t rest = long_rows; rest != 0; rest &= rest - 1) {
-        const int q = __builtin_ctzll(rest);
-        const int32_t q_src = __builtin_amdgcn_readlane(my_src, q), q_dst = __builtin_amdgcn_readlane(my_dst, q), q_len = __builtin_amdgcn_readlane(my_len, q);
-        for (int32_t off = 16 * (int32_t)lane; off < q_len; off += 16 * 64) {
-          const int32_t left = q_len - off;
-          if ((int64_t)q_src + off + 16 <= src_total) {
-            stage_piece(src_bytes + q_src + off, s_stage[wave] + (q_dst - a0) + off, left < 16 ? left : 16);
-          } else {  // the source's last bytes: one at a time
-            for (int32_t b = 0; b < left && b < 16; ++b) s_stage[wave][(q_dst - a0) + off + b] = src_bytes[q_src + off + b];
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      if (lane == 0) s_dst[wave][rows] = n_end;
+      fetch_offsets(c + 1);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's own LDS writes, before its reads below
       __builtin_amdgcn_wave_barrier();
-      for (int32_t p4 = a0 + 4 * (int32_t)lane; p4 < d1; p4 += 256) {
-        const uint32_t word = *(const uint32_t *)(s_stage[wave] + (p4 - a0));
-        if (p4 >= d0 && p4 + 4 <= d1) {
-          *(uint32_t *)(dst_bytes + p4) = word;
-        } else {
+      utf8_copy_chunk(col.src_bytes, col.src_total, col.out_bytes, i < m, my_src, my_len, my_dst, s_dst[wave], s_src[wave], s_stage[wave], rows, lane);
+      __builtin_amdgcn_wave_barrier();  // the next column (or chunk) overwrites the offsets and the staging row
+    }
+  }
+}
+
+// Offsets and bytes in one pass, for a caller that has the output bytes' buffers before it knows how many there are (a
+// Selection that does not wait for its row count sizes them by the source): a tile's rows are scanned and placed as in
+// the offsets kernel, and the workgroup then copies their bytes itself, a wave to 64 consecutive rows at a time - the
+// source offsets, the output offsets and the row ids are in its registers, where the two-kernel form reads them from
+// memory a second time (per selected row and column: 8 bytes of source offsets, scattered, 4 of output offsets, 4 of
+// row id) and pays a launch's tail twice.
+// (a tile of 2048 rows, three workgroups - 24 waves - to a compute unit, which is what their LDS allows: 6.3 ms for the ten
+// string columns of 100 M rows, 7.1 for offsets and bytes in a launch each; tiles of 4096 rows with two workgroups to a
+// unit 7.3, tiles of 1024 with six 7.0: fewer waves to hide the fetches behind, or more look-backs)
+constexpr int FUSED_THREADS = 512, FUSED_R = 4;
+constexpr size_t FUSED_WAVE_LDS = 64 * GATHER_SHORT + 16 + (64 * FUSED_R + 4) * 4 + 64 * FUSED_R * 4;
+__global__ __launch_bounds__(FUSED_THREADS) void qe_utf8_gather_fused_kernel(const Utf8GatherCols C, const int32_t *idx, int64_t m_bound,
+                                                                             const unsigned long long *m_dev) {
+  constexpr int R = FUSED_R, TILE = FUSED_THREADS * R, WAVES = FUSED_THREADS / 64;
+  const int64_t m = m_dev ? (int64_t)__hip_atomic_load(m_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : m_bound;
+  const int64_t n_tiles = (m + TILE - 1) / TILE;
+  if (m <= 0) {  // no tile ever writes offsets[m] = offsets[0] then
+    if (blockIdx.x == 0 && (int)threadIdx.x < C.n) C.col[threadIdx.x].out_offsets[0] = 0;
+    return;
+  }
+  constexpr uint32_t LANES_A_WORD = 32 / R;  // lanes whose rows share one 32-row validity word
+  __shared__ int32_t s_wave[WAVES];
+  __shared__ unsigned long long s_tile, s_base;
+  // per wave (dynamic LDS, FUSED_WAVE_LDS bytes each): the staging row, the output offsets of the wave's rows (and where
+  // they end), their source offsets
+  extern __shared__ __attribute__((aligned(16))) uint8_t fused_lds[];
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  uint8_t *const my_stage = fused_lds + (size_t)wave * FUSED_WAVE_LDS;
+  int32_t *const my_dst_row = (int32_t *)(my_stage + 64 * GATHER_SHORT + 16);
+  int32_t *const my_src_row = my_dst_row + 64 * R + 4;
+  FilterScratch *const tickets = (FilterScratch *)C.col[0].control;
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(&tickets->ticket, 1ull);
+    __syncthreads();
+    const int64_t ticket = (int64_t)s_tile;
+    const int64_t tile = ticket / C.n;
+    if (tile >= n_tiles) break;
+    const Utf8GatherCol &col = C.col[ticket - tile * C.n];
+    const int32_t *const src_offsets = col.src_offsets;
+    const uint8_t *const src_validity = col.src_validity;
+    int32_t *const out_offsets = col.out_offsets;
+    uint32_t *const out_validity = src_validity ? col.out_validity : nullptr;
+    FilterScratch *const scratch = (FilterScratch *)col.control;
+    unsigned long long *const status = (unsigned long long *)col.status;
+    const int64_t i0 = tile * TILE + (int64_t)threadIdx.x * R;
+    const bool whole = i0 + R <= m;
+    int64_t r[R];
+    if (whole) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (p4 + k >= d0 && p4 + k < d1) dst_bytes[p4 + k] = (uint8_t)(word >> (8 * k));
-        }
+      for (int k = 0; k < R; k += 4) {
+        const I32x4 four = *(const I32x4 *)__builtin_assume_aligned(idx + i0 + k, 16);
+        r[k] = four.a, r[k + 1] = four.b, r[k + 2] = four.c, r[k + 3] = four.d;
       }
     } else {
-      // ---- a run too long for the staging row: a lane takes four consecutive output bytes (one aligned dword store; the
-      // run's ragged ends go out byte by byte: the bytes next to them belong to other waves) and finds each byte's row
-      for (int32_t p4 = a0 + 4 * (int32_t)lane; p4 < d1; p4 += 256) {
-        const uint32_t word = utf8_gather_dword(sd, ss, rows, d0, d1, p4, src_bytes);
-        if (p4 >= d0 && p4 + 4 <= d1) {
-          *(uint32_t *)(dst_bytes + p4) = word;
-        } else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (p4 + k >= d0 && p4 + k < d1) dst_bytes[p4 + k] = (uint8_t)(word >> (8 * k));
+      for (int k = 0; k < R; ++k) r[k] = i0 + k < m ? (int64_t)idx[i0 + k] : -1;
+    }
+    int32_t len[R];
+    int32_t sum = 0;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      len[k] = 0;
+      int32_t two[2] = {0, 0};  // offsets r and r + 1 in one (unaligned) 8-byte load
+      if (r[k] >= 0) {
+        __builtin_memcpy(two, src_offsets + r[k], 8);
+        len[k] = two[1] - two[0];
+        if (out_validity) bits |= ((src_validity[r[k] >> 3] >> (r[k] & 7)) & 1u) << k;
+      }
+      my_src_row[R * lane + k] = two[0];
+      sum += len[k];
+    }
+    if (out_validity) {
+      uint32_t w = bits << (R * (lane & (LANES_A_WORD - 1)));
+#pragma unroll
+      for (uint32_t o = 1; o < LANES_A_WORD; o <<= 1) w |= __shfl_xor(w, o);
+      if ((lane & (LANES_A_WORD - 1)) == 0 && i0 < m) out_validity[i0 >> 5] = w;
+    }
+    int32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t t = __shfl_up(incl, o);
+      if ((int)lane >= o) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      if ((uint32_t)w < wave) woff += s_wave[w];
+      total += s_wave[w];
+    }
+    if (wave == 0) {
+      const unsigned long long excl = lookback_exclusive(status, tile, (unsigned long long)total, lane, &scratch->error);
+      if (lane == 0) {
+        s_base = excl;
+        if (tile == n_tiles - 1) {
+          scratch->total = excl + (unsigned long long)total;
+          out_offsets[m] = (int32_t)(excl + (unsigned long long)total);
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();  // the next column (or chunk) overwrites the offsets and the staging row
+    __syncthreads();
+    int32_t run = (int32_t)s_base + woff + incl - sum;
+    {
+      int32_t at = run;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        my_dst_row[R * lane + k] = at;
+        at += len[k];
+      }
+      if (lane == 63) my_dst_row[64 * R] = at;
+    }
+    if (whole) {
+#pragma unroll
+      for (int k = 0; k < R; k += 4) {
+        I32x4 four;
+        four.a = run, four.b = run + len[k], four.c = four.b + len[k + 1], four.d = four.c + len[k + 2];
+        run = four.d + len[k + 3];
+        *(I32x4 *)__builtin_assume_aligned(out_offsets + i0 + k, 16) = four;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        if (i0 + k < m) out_offsets[i0 + k] = run;
+        run += len[k];
+      }
+    }
+    // ---- the bytes of the wave's 64 R rows, 64 rows at a time
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave's own LDS writes, before its reads below
+    __builtin_amdgcn_wave_barrier();
+    const int64_t w0 = tile * TILE + (int64_t)wave * 64 * R;  // the wave's first row
+#pragma unroll 1
+    for (int c = 0; c < R; ++c) {
+      const int64_t first = w0 + 64 * c;
+      if (first >= m) break;
+      const int rows = (int)(m - first < 64 ? m - first : 64);
+      const int32_t *sd = my_dst_row + 64 * c, *ss = my_src_row + 64 * c;
+      const bool valid = (int)lane < rows;
+      // (rows beyond m hold a length of 0 and the offset the last real row ends at: sd[rows] is where the chunk ends)
+      const int32_t my_src = ss[lane], my_dst = sd[lane], my_len = valid ? sd[lane + 1] - my_dst : 0;
+      utf8_copy_chunk(col.src_bytes, col.src_total, col.out_bytes, valid, my_src, my_len, my_dst, sd, ss, my_stage, rows, lane);
+      __builtin_amdgcn_wave_barrier();  // the next chunk overwrites the staging row
     }
   }
 }
@@ -2034,6 +2187,31 @@ hipError_t launch_exclusive_scan_i32(int32_t *data, int64_t n, int32_t *block_su
   hipError_t e = launch_exclusive_scan_i32(block_sums, blocks, block_sums + blocks, stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(qe_scan_add_kernel, dim3((unsigned)blocks), dim3(SCAN_BLOCK), 0, stream, data, n, block_sums);
+  return hipGetLastError();
+}
+
+bool utf8_gather_fused_available() {
+  static int on = tuned("QE_UTF8_GATHER_FUSED", 1);  // 2: off (offsets and bytes in a launch each)
+  return on != 2;
+}
+
+hipError_t launch_utf8_gather_fused(const Utf8GatherCols &cols, const int32_t *idx, int64_t m, const unsigned long long *m_dev, int cus, hipStream_t stream) {
+  if (cols.n <= 0 || cols.n > UTF8_GATHER_MAX_COLS || ((uintptr_t)idx & 15)) return hipErrorInvalidValue;
+  if (m <= 0) return hipSuccess;
+  for (int i = 0; i < cols.n; ++i)
+    if (((uintptr_t)cols.col[i].out_offsets & 15) || cols.col[i].out_bytes == nullptr) return hipErrorInvalidValue;
+  static_assert(FUSED_THREADS * FUSED_R >= OFFSETS_TILE_MIN, "the status array is sized for tiles of OFFSETS_TILE_MIN rows");
+  const int64_t tiles = (m + FUSED_THREADS * FUSED_R - 1) / (FUSED_THREADS * FUSED_R) * cols.n;
+  static int per_cu = tuned("QE_UTF8_GATHER_FUSED_BLOCKS_PER_CU", 3);
+  const int64_t most = (int64_t)cus * per_cu;
+  const size_t lds = FUSED_WAVE_LDS * (FUSED_THREADS / 64);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)qe_utf8_gather_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(qe_utf8_gather_fused_kernel, dim3((unsigned)(tiles < most ? tiles : most)), dim3(FUSED_THREADS), lds, stream, cols, idx, m, m_dev);
   return hipGetLastError();
 }
 
