@@ -604,7 +604,9 @@ def extra_configs(qe, ctx, torch, dev, k, a, b, c, n, args):
     def entry(name, rows, dt, prof, kernel, bpr, launches_per_step, extra=None, steps=5):
         kernel, kk = dominant_kernel(prof, kernel)
         avg = kk["ms"] / kk["launches"] if kk["launches"] else float("nan")
-        gbs = bpr * rows / launches_per_step / (avg * 1e-3) / 1e9 if kk["launches"] else float("nan")
+        # (the kernel's time per step, whatever the number of its launches: several batches may share one launch, and a
+        # many-groups aggregate has a short trial launch of the same kernel in front)
+        gbs = bpr * rows / (kk["ms"] / steps * 1e-3) / 1e9 if kk["launches"] else float("nan")
         e2e = bpr * rows / dt / 1e9
         # frac_hbm_peak_end_to_end: algorithmic bytes / whole step (every kernel, every host wait) - the figure to judge a
         # multi-kernel configuration by; frac_hbm_peak_main_kernel: the same bytes over the dominant kernel's time alone

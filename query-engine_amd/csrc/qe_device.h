@@ -1326,20 +1326,25 @@ __device__ __forceinline__ uint32_t lds_pair_find_or_claim_rows(const LdsTable &
     const U64x2 two = *(const U64x2 *)__builtin_assume_aligned(&L.keys[any ? bb : 0u], 16);
     const bool h0 = any && two.x == kk, h1 = any && two.y == kk;
     const bool e0 = two.x == AGG_EMPTY_KEY, e1 = two.y == AGG_EMPTY_KEY;
-    bool found = h0 || h1, gone = false;
+    bool found = h0 || h1, gone = false, fresh = false;
     uint32_t at = bb + (h0 ? 0u : 1u);
     if (any && !found && (e0 || e1)) {
       // a new key: the bucket's first empty slot, if the table still takes keys
       at = bb + (e0 ? 0u : 1u);
       if (*(volatile uint32_t *)L.used < L.limit) {
         const unsigned long long old = atomicCAS(&L.keys[at], AGG_EMPTY_KEY, (unsigned long long)kk);
-        if (old == AGG_EMPTY_KEY) atomicAdd(L.used, 1u);
-        found = old == AGG_EMPTY_KEY || old == kk;  // (lost to another key: the same bucket once more - its other slot may be free)
+        fresh = old == AGG_EMPTY_KEY;
+        found = fresh || old == kk;  // (lost to another key: the same bucket once more - its other slot may be free)
       } else {
         gone = true;
       }
     } else if (any && !found) {
       bb = (bb + 2u) & mask;
+    }
+    {
+      // (the wave's claims counted with one atomic, not lane by lane on one LDS address)
+      const uint64_t claims = __ballot(fresh);
+      if (claims != 0 && lane_id() == (uint32_t)__builtin_ctzll(claims)) atomicAdd(L.used, (uint32_t)__popcll(claims));
     }
     const uint32_t bit = any ? 1u << jj : 0u;
     hit |= found ? bit : 0u;
@@ -1408,7 +1413,7 @@ __device__ __forceinline__ uint32_t lds_two_pairs_find_or_claim4(const LdsTable 
   if (__ballot(want != 0) != 0 && *(volatile uint32_t *)L.used < L.limit) {
 #pragma unroll
     for (int j = 0; j < VM_R; ++j) {
-      bool got = false;
+      bool got = false, fresh = false;
       if ((want >> j) & 1u) {
         bool admit = *(volatile uint32_t *)L.used < L.limit;
         if (admit && L.door) {
@@ -1422,10 +1427,14 @@ __device__ __forceinline__ uint32_t lds_two_pairs_find_or_claim4(const LdsTable 
         }
         if (admit) {
           const unsigned long long old = atomicCAS(&L.keys[b[j]], AGG_EMPTY_KEY, (unsigned long long)key[j]);
-          if (old == AGG_EMPTY_KEY) atomicAdd(L.used, 1u);
-          got = old == AGG_EMPTY_KEY || old == key[j];
+          fresh = old == AGG_EMPTY_KEY;
+          got = fresh || old == key[j];
         }
       }
+      // (the wave's claims counted with one atomic: lane by lane they are as many operations on one LDS address, one
+      // after the other - while a table fills, most of what its workgroup does)
+      const uint64_t claims = __ballot(fresh);
+      if (claims != 0 && lane_id() == (uint32_t)__builtin_ctzll(claims)) atomicAdd(L.used, (uint32_t)__popcll(claims));
       slot8[j] = got ? b[j] * 8u : slot8[j];
       hit |= got ? 1u << j : 0u;
     }

@@ -1076,7 +1076,8 @@ static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &b
     const char *e = getenv("QE_SPILL_REGION_PAD");
     return e ? atoi(e) : 0;
   }();
-  a.rows_per_wave = (uint32_t)(steps_per_wave * VM_WAVE_ROWS + region_pad);
+  // (a launch over several batches deals each batch's steps to the waves anew: a step more per batch and wave at most)
+  a.rows_per_wave = (uint32_t)((steps_per_wave + (args.n_more > 0 ? args.n_more + 2 : 0)) * VM_WAVE_ROWS + region_pad);
   a.capacity = (uint64_t)sp.waves * a.rows_per_wave;
   a.n_inputs = (uint32_t)inputs.size();
   static const bool pairs_on = [] {
@@ -1465,6 +1466,7 @@ struct AggState {
       return e && atoll(e) > 0 ? (int64_t)atoll(e) : DIRECT_PROBE_ROWS;
     }();
     probe.n_rows = std::min<int64_t>(args.n_rows, probe_rows);
+    probe.n_more = 0;
     probe.tune |= 4u;  // the workgroups' tables are not flushed
     const size_t cells = spill_cells(sp.bits, sp.blocks);
     BufferPtr cell_buf = device_buffer(ctx, (cells + 1) * 4 + 64), ctrl = device_buffer(ctx, 256);
@@ -1582,11 +1584,31 @@ struct AggState {
 
   // Folds one batch in.  `outputs` (may be empty = the batch's columns) are the expressions the
   // group / aggregate expressions' column indices refer to; `pred` selects rows.
-  void update(const Batch &in_raw, const std::vector<ExprPtr> &outputs, const ExprPtr &pred) {
+  // `more` (optional): the batches that follow, which a many-groups first pass takes in the same launch when it can
+  // (its workgroups' tables are then filled and flushed once for all of them); otherwise they are folded in one by one.
+  void update(const Batch &in_raw, const std::vector<ExprPtr> &outputs, const ExprPtr &pred, const std::vector<Batch> *more = nullptr) {
     if (!parts.empty()) {
-      for (auto &p : parts) p->update(in_raw, outputs, pred);
+      for (auto &p : parts) {
+        p->update(in_raw, outputs, pred);
+        if (more)
+          for (auto &e : *more) p->update(e, outputs, pred);
+      }
       return;
     }
+    size_t more_taken = 0;  // batches of `more` that went into this batch's launch
+    struct FoldRest {       // (whatever did not, on every way out that is not an exception)
+      AggState *st;
+      const std::vector<ExprPtr> &outputs;
+      const ExprPtr &pred;
+      const std::vector<Batch> *more;
+      size_t &taken;
+      bool armed = true;
+      void run() {
+        armed = false;
+        if (more)
+          for (size_t i = taken; i < more->size(); ++i) st->update((*more)[i], outputs, pred);
+      }
+    } rest{this, outputs, pred, more, more_taken};
     Batch in = strict ? in_raw : without_redundant_validity(in_raw);
     ctx->bind();
     ensure_counters(ctx);
@@ -1662,6 +1684,7 @@ struct AggState {
       }
       for (size_t i = 0; i < aggs.size(); ++i) scales_now.push_back(fix_scale[i] == INT_MIN ? 0 : fix_scale[i]);
     }
+    bool had_temporaries = false;
     {
       // predicate, keys and accumulator inputs share one program: whatever exceeds it is evaluated beforehand
       std::vector<ExprPtr *> all;
@@ -1689,6 +1712,7 @@ struct AggState {
           if (g->kind != EK_COLUMN) g = fitter.materialise(g);
       fitter.fit_together(all, 12 + 5 * (int)g2.size() + (int)a2.size(), 4);
       if (fitter.temporaries) schema = fitter.schema;
+      had_temporaries = fitter.temporaries != 0;
     }
     AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode, row_base, emit_row_number, any_fix ? &scales_now : nullptr,
                                    any_fix && fix_overflow ? (uint64_t)(uintptr_t)fix_overflow->ptr : 0);
@@ -1742,15 +1766,59 @@ struct AggState {
           fail(QE_ERR_INVALID_ARGUMENT, "batches of one scan must share nullability");
         }
     }
-    if (in.rows == 0) return;
+    if (in.rows == 0) {
+      rest.run();
+      return;
+    }
     Compiler comp(ctx, &in);
     AggArgs args{};
     lower_aggregate(comp, schema, pred_n, bspec, spec, args);
     args.table = table;
     args.n_rows = in.rows;
+    // The batches that follow, in this launch: for the first passes of the many-groups mode, when the program reads
+    // nothing but its cached columns (they are all a further batch brings) and the batch is of the same shape -
+    // lowered against it, the same kernel signature and literals.  Row numbers (hashed keys' representatives, the
+    // parts of a split aggregation) count from each batch's own base: not for those.
+    int64_t rows_in_launch = in.rows;
+    static const bool merge_on = [] {
+      const char *e = getenv("QE_SPILL_MERGE_BATCHES");  // 0: a launch per batch
+      return e ? atoi(e) != 0 : true;
+    }();
+    if (more && merge_on && effective_hint() >= spill_min_group_hint() && bspec.key_gathers.empty() && !emit_row_number && !any_fix && !had_temporaries &&
+        comp.keepalive.empty() && comp.n_cols == (int)comp.prog.cache_n && in.rows >= (int64_t)ctx->dev.cus * VM_WAVE_ROWS * (AGG_WIDE_THREADS / 64)) {
+      const std::vector<uint32_t> sig = signature(args);
+      while (more_taken < more->size() && args.n_more < AGG_MORE_BATCHES) {
+        const Batch &e_raw = (*more)[more_taken];
+        if (e_raw.rows <= 0 || e_raw.cols.size() != in_raw.cols.size() || rows_in_launch + e_raw.rows > ((int64_t)1 << 30)) break;
+        Batch e = strict ? e_raw : without_redundant_validity(e_raw);
+        bool same = schema_of(e).size() == schema.size();
+        for (size_t i = 0; same && i < schema.size(); ++i) same = e.cols[i].type == in.cols[i].type;
+        if (!same) break;
+        Compiler comp_e(ctx, &e);
+        AggArgs args_e{};
+        lower_aggregate(comp_e, schema, pred_n, bspec, spec, args_e);
+        if (!comp_e.keepalive.empty() || comp_e.n_cols != (int)comp_e.prog.cache_n || comp_e.prog.cache_n != comp.prog.cache_n || signature(args_e) != sig ||
+            std::memcmp(args_e.prog.lits, args.prog.lits, sizeof(args.prog.lits)) != 0)
+          break;
+        for (uint32_t i = 0; i < comp_e.prog.cache_n; ++i) args.more_cols[args.n_more][i] = args_e.prog.cols[args_e.prog.cache_col[i]];
+        args.more_rows[args.n_more] = e.rows;
+        ++args.n_more;
+        rows_in_launch += e.rows;
+        ++more_taken;
+      }
+    }
     args.lds_cap = aggregate_lds_slots(args, ctx->dev, effective_hint(), false);
     args.lds_limit = args.lds_cap - args.lds_cap / 4;
+    args.n_rows = rows_in_launch;  // (what the log, the stretches and the launch are sized by)
     SpillPlan sp = plan_spill(ctx, schema, bspec, args, effective_hint(), true, direct_mode == 2);
+    if (args.n_more > 0 && !(sp.on && sp.groupable)) {
+      // not a first pass of the many-groups mode after all: the batches one by one
+      more_taken -= (size_t)args.n_more;
+      args.n_more = 0;
+      rows_in_launch = in.rows;
+      args.n_rows = in.rows;
+      sp = plan_spill(ctx, schema, bspec, args, effective_hint(), true, direct_mode == 2);
+    }
     if (sp.on && sp.groupable && !sp.direct && direct_mode == 0 && !direct_off && in.rows >= 8 * DIRECT_PROBE_ROWS && sp.blocks == ctx->dev.cus &&
         aggregate_direct_available(args, ctx->dev, sp.bits)) {
       choose_first_pass(args, sp);
@@ -1770,8 +1838,10 @@ struct AggState {
     }
     if (sp.on && sp.groupable) spill_attach(sp, args);
     else spill_flush();  // (a launch that goes another way: what is pending first, so that the table sees the batches in order)
+    args.n_rows = in.rows;  // (the first batch's; the others' in more_rows)
+    for (int i = 0; i < args.n_more; ++i) row_base += args.more_rows[i];
     const char *kname = "qe_aggregate_kernel";
-    ctx->prof_begin(kname, in.rows);
+    ctx->prof_begin(kname, rows_in_launch);
     if (sp.direct) {
       QE_HIP(launch_aggregate_direct(args, ctx->dev, ctx->stream, &kname));
       sp.counted = true;
@@ -1784,6 +1854,7 @@ struct AggState {
       else aggregate_spilled(ctx, sp, args, effective_hint());
     }
     if (!comp.keepalive.empty()) ctx->sync();
+    rest.run();
   }
 
   // The output without a word from the device: one row per table slot, the rows past the group count
@@ -2052,7 +2123,14 @@ struct AggIter : Iter {
       s.src->reset();
       Batch in;
       try {
-        while (s.src->next(in)) st.update(in, stream_outputs(s, (int)in.cols.size()), s.pred);
+        // (with very many groups up to four batches go to the device at a time: one launch of the first pass can take them all)
+        const bool ahead = st.effective_hint() >= spill_min_group_hint();
+        while (s.src->next(in)) {
+          std::vector<Batch> more;
+          Batch e;
+          while (ahead && in.rows > 0 && (int)more.size() < AGG_MORE_BATCHES && s.src->next(e)) more.push_back(e);
+          st.update(in, stream_outputs(s, (int)in.cols.size()), s.pred, more.empty() ? nullptr : &more);
+        }
       } catch (const NeedsStrictNullability &) {
         st.strict = true;  // a later batch has nulls where the earlier ones had none: once more, tracking them
         continue;

@@ -58,6 +58,18 @@ __device__ __forceinline__ void cache_fill_static(const VmProgram &P, const RowC
   }
 }
 
+// The same for batch `b` of a launch over several batches (AggArgs::n_more): batch 0's columns are the program's.
+template <class Spec, uint32_t MASK, int I>
+__device__ __forceinline__ void cache_fill_batch(const AggArgs &A, int b, const RowCtx &c, ColCache &K) {
+  if constexpr (I < Spec::cache_n) {
+    if constexpr ((MASK >> I) & 1u) {
+      const VmCol &col = b == 0 ? A.prog.cols[A.prog.cache_col[I]] : A.more_cols[b - 1][I];
+      cache_load_static<Spec::cache_kind[I], Spec::cache_nullable[I] != 0>(col, c, K.v[I], K.valid[I]);
+    }
+    cache_fill_batch<Spec, MASK, I + 1>(A, b, c, K);
+  }
+}
+
 template <class Spec, uint32_t MASK, int I>
 __device__ __forceinline__ void cache_copy_static(ColCache &dst, const ColCache &src) {
   if constexpr (I < Spec::cache_n) {
@@ -907,7 +919,6 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_spill_static
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t n_waves = blockDim.x >> 6;
-  const int64_t n = A.n_rows;
   LdsTable L;
   agg_lds_setup(L, lds_raw, A.lds_cap, A.lds_limit, Spec::n_accs, spec_tracks_validity<Spec>());
   if (A.door_off != 0) L.door = (uint16_t *)((char *)lds_raw + A.door_off);
@@ -916,9 +927,11 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_spill_static
     for (uint32_t p = threadIdx.x; p < (1u << A.cell_bits); p += blockDim.x) hist[p] = 0;
   agg_lds_clear(L, A.accs, Spec::n_accs);  // ends with a barrier
   SpillState sp = spill_begin(A.spill, wave);
-  const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
   uint32_t turn = wave >> 2;  // (waves 4 apart share a SIMD)
   uint32_t selected = 0;      // rows of this wave that passed the predicate with a valid key (wave-uniform)
+  for (int batch = 0; batch <= A.n_more; ++batch) {  // (the launch's batches one after the other: the table stays)
+  const int64_t n = batch == 0 ? A.n_rows : A.more_rows[batch - 1];
+  const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
   for (int64_t ws = (int64_t)blockIdx.x * n_waves + wave; ws < nsteps; ws += (int64_t)gridDim.x * n_waves) {
     if (A.tune & 8u) {
       // The four waves of a SIMD take the high priority in turn, a step each.  Left alone the oldest wave is served
@@ -937,7 +950,7 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_spill_static
     c.lane = lane;
     c.active = in_range_bits(c.row0, lane, n);
     ColCache K;
-    cache_fill_static<Spec, (1u << Spec::cache_n) - 1u, 0>(A.prog, c, K);
+    cache_fill_batch<Spec, (1u << Spec::cache_n) - 1u, 0>(A, batch, c, K);
     SpillRows G;
 #pragma unroll
     for (int j = 0; j < VM_R; ++j) G.key[j] = 0, G.slot8[j] = 0;
@@ -950,6 +963,7 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_spill_static
     spill_tasks_static<Spec, 0>(A, L, c, K, G, in, sp, hist);
 #pragma unroll
     for (int j = 0; j < VM_R; ++j) selected += (uint32_t)__popcll(__ballot((((G.hit | G.miss) >> j) & 1u) != 0));
+  }
   }
   spill_end(A.spill, sp, wave, lane);
   if (hist) {
@@ -1030,7 +1044,6 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_direct_stati
   uint32_t *s_ready = s_valid + P;                                               // [2 P] lines to write this round: partition | line number << 9
   uint32_t *s_nready = s_ready + 2 * P;                                          // [2] their number, rounds taking turns
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-  const int64_t n = A.n_rows;
   const uint32_t cap = A.spill.direct_cap;
   KeyVal *dst = (KeyVal *)A.spill.keys;
   auto stretch = [&](uint32_t p) { return ((uint64_t)p * gridDim.x + blockIdx.x) * cap; };
@@ -1092,6 +1105,9 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_direct_stati
     ++turn;
   };
 
+  uint32_t dropped = 0;
+  for (int batch = 0; batch <= A.n_more; ++batch) {  // (the launch's batches one after the other: the rings stay)
+  const int64_t n = batch == 0 ? A.n_rows : A.more_rows[batch - 1];
   const int64_t nsteps = (n + VM_WAVE_ROWS - 1) / VM_WAVE_ROWS;
   const int64_t steps_a_round = (int64_t)gridDim.x * n_waves;
   const int64_t rounds = (nsteps + steps_a_round - 1) / steps_a_round;  // the same for every wave: barriers inside
@@ -1100,13 +1116,12 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_direct_stati
     c.n = n;
     c.lane = lane;
     c.active = in_range_bits(c.row0, lane, n);  // (nothing beyond the last step)
-    cache_fill_static<Spec, (1u << Spec::cache_n) - 1u, 0>(A.prog, c, K);
+    cache_fill_batch<Spec, (1u << Spec::cache_n) - 1u, 0>(A, batch, c, K);
   };
   int64_t ws = (int64_t)blockIdx.x * n_waves + wave;
   RowCtx cn;
   ColCache Kn;
   fetch(ws, cn, Kn);
-  uint32_t dropped = 0;
   for (int64_t r = 0; r < rounds; ++r) {
     RowCtx c;
     c.row0 = cn.row0;
@@ -1153,6 +1168,7 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_direct_stati
     }
     lds_barrier();
     flush(false);
+  }
   }
   flush(true);
   // what this workgroup wrote, per partition

@@ -234,6 +234,8 @@ struct AggSpill {
   uint32_t direct_pad;
 };
 
+constexpr int AGG_MORE_BATCHES = 3;  // batches a first pass of the many-groups mode takes on top of its first
+
 struct AggArgs {
   VmProgram prog;
   VmKey keys[VM_MAX_KEYS];
@@ -263,6 +265,14 @@ struct AggArgs {
   // Columns in a row of the cell table (0 = the launch's workgroups).  Several launches whose logs are partitioned
   // together share one table, each with a block of columns of its own: `cells` then points at this launch's first.
   uint32_t cells_stride;
+  // Further batches a many-groups first pass takes in the same launch - its workgroups' tables, filled and flushed
+  // once, serve them all - when the program reads cached columns only: batch b (1 .. n_more) has more_rows[b - 1]
+  // rows and its columns, by cache slot, in more_cols[b - 1].  The log's regions and the stretches are sized for
+  // the rows of all of them.
+  int32_t n_more;
+  int32_t more_pad;
+  int64_t more_rows[AGG_MORE_BATCHES];
+  VmCol more_cols[AGG_MORE_BATCHES][VM_NCACHE];
 };
 
 // Does the workgroup's LDS table keep per-accumulator counts of valid inputs?  Host and device size the table alike.

@@ -189,8 +189,13 @@ def test_lean_first_pass_of_the_high_cardinality_mode(qe):
         names = set(jit.profile_read())
         assert any(k.startswith("qe_aggregate_spill_static<") for k in names), names
         assert "qe_spill_count_kernel" not in names and "qe_aggregate_partitioned_kernel" in names, names
-        # (a small second batch: too few workgroups for one per column of the cell table, so its rows are counted by the count pass)
+        # (a second batch of the same shape goes into the first one's launch: one first pass for both)
         run_agg(qe, jit, [kz, [orc.Array(a.type, a.values[:50_000]) for a in kz]], [C(0)], four, hint=hint, what="lean four, two batches")
+        prof = jit.profile_read()
+        assert "qe_spill_count_kernel" not in prof and sum(v["launches"] for k, v in prof.items() if k.startswith("qe_aggregate_spill_static<")) == 1, prof
+        # (a small batch first: too few workgroups for one per column of the cell table, so it has a launch of its own and
+        # its rows are counted by the count pass)
+        run_agg(qe, jit, [[orc.Array(a.type, a.values[:50_000]) for a in kz], kz], [C(0)], four, hint=hint, what="lean four, a small batch first")
         assert "qe_spill_count_kernel" in set(jit.profile_read())
         # a run-time compiled shape: seven aggregates over three inputs behind a filter
         cols = [orc.Array(orc.INT64, k), orc.Array(orc.FLOAT64, z), orc.Array(orc.FLOAT64, x), orc.Array(orc.INT64, y)]
