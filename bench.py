@@ -456,7 +456,7 @@ def main():
     kname, kern = dominant_kernel(prof, "qe_aggregate")
     launches = kern["launches"]
     avg_ms = kern["ms"] / launches if launches else float("nan")
-    rows_per_launch = n / len(batches)
+    rows_per_launch = n * args.steps / launches if launches else float("nan")  # (a launch may take several batches)
     achieved = BYTES_PER_ROW["c5"] * rows_per_launch / (avg_ms * 1e-3) / 1e9 if launches else float("nan")
 
     traffic, traffic_src = measured_traffic(kname, rows_per_launch)

@@ -1784,6 +1784,9 @@ struct AggState {
       const char *e = getenv("QE_SPILL_MERGE_BATCHES");  // 0: a launch per batch
       return e ? atoi(e) != 0 : true;
     }();
+    // (Only there: with few groups a launch's fixed costs are small - one launch of the headline plan over four batches
+    // measured 1 to 3 % faster than four, within the spread from run to run, and the batch loop cost the kernel ten
+    // registers.)
     if (more && merge_on && effective_hint() >= spill_min_group_hint() && bspec.key_gathers.empty() && !emit_row_number && !any_fix && !had_temporaries &&
         comp.keepalive.empty() && comp.n_cols == (int)comp.prog.cache_n && in.rows >= (int64_t)ctx->dev.cus * VM_WAVE_ROWS * (AGG_WIDE_THREADS / 64)) {
       const std::vector<uint32_t> sig = signature(args);
@@ -1812,7 +1815,7 @@ struct AggState {
     args.n_rows = rows_in_launch;  // (what the log, the stretches and the launch are sized by)
     SpillPlan sp = plan_spill(ctx, schema, bspec, args, effective_hint(), true, direct_mode == 2);
     if (args.n_more > 0 && !(sp.on && sp.groupable)) {
-      // not a first pass of the many-groups mode after all: the batches one by one
+      // not a first pass of the many-groups mode after all (or one whose log is partitioned batch by batch): the batches one by one
       more_taken -= (size_t)args.n_more;
       args.n_more = 0;
       rows_in_launch = in.rows;

@@ -2001,6 +2001,7 @@ hipError_t launch_aggregate(const AggArgs &args_in, const DeviceInfo &dev, hipSt
   if (jit_wanted(dev, args.n_rows) &&
       jit_launch(JIT_AGGREGATE, spec_fields(args), &args, dev.jit, dev.device, grid, VM_BLOCK_THREADS, lds, stream, &err, kernel_name))
     return err;
+  if (args.n_more > 0) return hipErrorInvalidConfiguration;  // (the interpreter kernels take one batch: aggregate_takes_more_batches said otherwise?)
   if (program_needs_full(args.prog))
     hipLaunchKernelGGL(qe_aggregate_kernel<true>, dim3(grid), dim3(VM_BLOCK_THREADS), lds, stream, args);
   else
