@@ -968,16 +968,25 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_spill_static
   spill_end(A.spill, sp, wave, lane);
   if (hist) {
     // this workgroup's column of the partition passes' cell table, and its share of the log's length
+    // (one atomic a workgroup: a wave each are four thousand operations on one word of memory as the launch ends,
+    // a tenth of a millisecond in which nothing else happens)
+    __shared__ unsigned long long s_logged, s_selected;
+    if (threadIdx.x == 0) s_logged = 0, s_selected = 0;
     __syncthreads();
     const uint32_t cells_stride = A.cells_stride ? A.cells_stride : gridDim.x;
     for (uint32_t p = threadIdx.x; p < (1u << A.cell_bits); p += blockDim.x) A.cells[(size_t)p * cells_stride + blockIdx.x] = (int32_t)hist[p];
 #ifdef QE_ABLATE
     if (A.tune & 0x150u) sp.cursor = 0;  // (the log is not what the histogram says: the partition passes see none)
 #endif
-    if (lane == 0 && sp.cursor != 0) atomicAdd(A.cells_total, (unsigned long long)sp.cursor);
+    if (lane == 0 && sp.cursor != 0) atomicAdd(&s_logged, (unsigned long long)sp.cursor);
     // (a launch with a block of columns in a shared cell table also says how many rows it saw: logged / selected is what
     // the host chooses between this kernel and the one that partitions directly by)
-    if (lane == 0 && selected != 0 && A.cells_stride != 0) atomicAdd(A.cells_total + 2, (unsigned long long)selected);
+    if (lane == 0 && selected != 0) atomicAdd(&s_selected, (unsigned long long)selected);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (s_logged != 0) atomicAdd(A.cells_total, s_logged);
+      if (s_selected != 0 && A.cells_stride != 0) atomicAdd(A.cells_total + 2, s_selected);
+    }
   }
   if (!(A.tune & 4u)) agg_flush(L, A.table, A.accs, Spec::n_accs);  // (bit 2: a launch whose results are thrown away - the host's look at how many rows miss the tables)
 }
@@ -1184,9 +1193,13 @@ __global__ __launch_bounds__(AGG_WIDE_THREADS, 4) void qe_aggregate_direct_stati
     mine += got < cap ? got : cap;
   }
   if (__ballot(dropped != 0) != 0 && lane == 0) atomicOr(A.spill.counts, 1u);
-  // (the total of the rows written: sizes nothing, but says how selective the batch was)
+  // (the total of the rows written: sizes nothing, but says how selective the batch was; one atomic a workgroup)
   for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
-  if (lane == 0 && mine != 0) atomicAdd(A.cells_total, (unsigned long long)mine);
+  if (threadIdx.x == 0) s_nready[0] = 0;  // (the list's counter: free by now - the last flush ended with a barrier)
+  lds_barrier();
+  if (lane == 0 && mine != 0) atomicAdd(&s_nready[0], mine);
+  lds_barrier();
+  if (threadIdx.x == 0 && s_nready[0] != 0) atomicAdd(A.cells_total, (unsigned long long)s_nready[0]);
 }
 
 }  // namespace qe
