@@ -74,7 +74,7 @@ def check_against_torch(torch, k, v, keep, got, with_min_max):
         assert np.array_equal(got[4], ref_min) and np.array_equal(got[5], ref_max)
 
 
-@pytest.mark.parametrize("n_batches", [1, 2, 3])
+@pytest.mark.parametrize("n_batches", [1, 2, 3, 6])
 def test_uniform_keys_take_the_partitioning_first_pass(qe, torch_ctx, n_batches):
     torch, ctx = torch_ctx
     n = 72_000_001  # (ragged: the last wave-step is partial, the batches differ in size)
