@@ -147,6 +147,10 @@ void batch_settle(Batch &b) {
 Context::~Context() {
   (void)hipSetDevice(device);
   (void)hipStreamSynchronize(stream);
+  if (copy_stream) {
+    (void)hipStreamSynchronize(copy_stream);
+    (void)hipStreamDestroy(copy_stream);
+  }
   for (hipEvent_t e : pending_events) (void)hipEventDestroy(e);
   for (unsigned long long *slab : pending_slabs) (void)hipHostFree(slab);
   for (auto &r : launches) {
@@ -157,6 +161,8 @@ Context::~Context() {
     for (void *q : kv.second) (void)hipFree(q);
   for (Staging &s : staging) {
     if (s.copied) (void)hipEventDestroy(s.copied);
+    if (s.fence) (void)hipEventDestroy(s.fence);
+    if (s.images) (void)hipEventDestroy(s.images);
     if (s.ptr) (void)hipHostFree(s.ptr);
   }
   if (filter_scratch) (void)hipFree(filter_scratch);

@@ -42,8 +42,13 @@ struct Context : std::enable_shared_from_this<Context> {
     size_t cap = 0;
     hipEvent_t copied = nullptr;  // recorded after the copy out of the buffer
     bool pending = false;
+    // for a chunk that reader threads copy to the device slice by slice, on the copy stream: `fence` orders those
+    // copies behind whatever the context's stream still does with the device block they go to, `images` is recorded
+    // behind the last of them
+    hipEvent_t fence = nullptr, images = nullptr;
   };
-  static constexpr int STAGING_BUFFERS = 6;
+  hipStream_t copy_stream = nullptr;  // host -> device copies of file scans, beside the context's stream (made on first use)
+  static constexpr int STAGING_BUFFERS = 8;
   Staging staging[STAGING_BUFFERS];
   int next_staging = 0;
   // Plain host memory that scans reuse for compressed bytes (a fresh allocation per column chunk

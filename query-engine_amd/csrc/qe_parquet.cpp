@@ -15,6 +15,10 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -383,12 +387,53 @@ size_t io_threads() {
       cpu_set_t set;
       CPU_ZERO(&set);
       long allowed = sched_getaffinity(0, sizeof set, &set) == 0 ? (long)CPU_COUNT(&set) : (long)std::thread::hardware_concurrency();
-      v = std::min<long>(16, std::max<long>(1, allowed));
+      // (one CPU is left to the thread that runs the scan when the process has sixteen or fewer)
+      v = std::min<long>(16, std::max<long>(1, allowed <= 16 ? allowed - 1 : allowed));
     }
     return (size_t)std::min<long>(v, 64);
   }();
   return n;
 }
+
+// The host threads of the bulk jobs, started once and kept: column chunks are read in slices by up to sixteen of them
+// (jobs are taken in the order they were handed in, so the slices of the chunks read ahead land in file order), and
+// page decompression runs on them.  Never torn down (the threads wait on a condition variable until the process ends);
+// its jobs never wait for other jobs of the pool, so callers on any thread may share it.
+class IoPool {
+ public:
+  static IoPool &get() {
+    static IoPool *pool = new IoPool();
+    return *pool;
+  }
+  void submit(std::function<void()> job) {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      jobs_.push_back(std::move(job));
+    }
+    cv_.notify_one();
+  }
+
+ private:
+  IoPool() {
+    const size_t n = io_threads();
+    for (size_t i = 0; i < n; ++i)
+      std::thread([this] {
+        for (;;) {
+          std::function<void()> job;
+          {
+            std::unique_lock<std::mutex> g(m_);
+            cv_.wait(g, [this] { return !jobs_.empty(); });
+            job = std::move(jobs_.front());
+            jobs_.pop_front();
+          }
+          job();
+        }
+      }).detach();
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> jobs_;
+};
 
 template <typename F>
 void parallel_for(size_t n, F fn) {
@@ -397,27 +442,40 @@ void parallel_for(size_t n, F fn) {
     for (size_t i = 0; i < n; ++i) fn(i);
     return;
   }
-  std::atomic<size_t> next{0};
-  std::exception_ptr err;
-  std::mutex m;
-  auto work = [&] {
+  struct Shared {
+    std::atomic<size_t> next{0};
+    std::exception_ptr err;
+    std::mutex m;
+    std::condition_variable done;
+    size_t helpers_left = 0;
+  };
+  auto sh = std::make_shared<Shared>();
+  auto work = [sh, n, &fn] {
     try {
       for (;;) {
-        const size_t i = next.fetch_add(1);
+        const size_t i = sh->next.fetch_add(1);
         if (i >= n) break;
         fn(i);
       }
     } catch (...) {
-      std::lock_guard<std::mutex> g(m);
-      if (!err) err = std::current_exception();
-      next.store(n);
+      std::lock_guard<std::mutex> g(sh->m);
+      if (!sh->err) sh->err = std::current_exception();
+      sh->next.store(n);
     }
   };
-  std::vector<std::thread> threads;
-  for (size_t k = 0; k + 1 < t; ++k) threads.emplace_back(work);
+  sh->helpers_left = t - 1;
+  for (size_t k = 0; k + 1 < t; ++k)
+    IoPool::get().submit([sh, work] {
+      work();  // (`fn` lives until the caller has seen every helper leave: it waits below)
+      std::lock_guard<std::mutex> g(sh->m);
+      if (--sh->helpers_left == 0) sh->done.notify_all();
+    });
   work();
-  for (auto &th : threads) th.join();
-  if (err) std::rethrow_exception(err);
+  {
+    std::unique_lock<std::mutex> g(sh->m);
+    sh->done.wait(g, [&] { return sh->helpers_left == 0; });
+  }
+  if (sh->err) std::rethrow_exception(sh->err);
 }
 
 // The staging buffer to fill next, at least `bytes` large; waits until the copy that last read it is done.
@@ -492,12 +550,31 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
   uint8_t *raw;
   Context::Staging *stage = nullptr;
   (void)table_room;
+  BufferPtr dev;          // the chunk's image on the device, then its tables
+  size_t dev_copied = 0;  // bytes of the staging buffer that are on their way there already
   if (ahead && ahead->stage) {
-    // read ahead of time into a staging buffer of its own: wait for the reader (its failure is thrown here)
+    // Read ahead of time into a staging buffer of its own, and copied to the device slice by slice by its readers:
+    // wait until the last of those copies has been queued (a reader's failure is thrown here, once its fellow readers
+    // are through), and put this stream's work on the chunk behind them.
     stage = ahead->stage;
     raw = (uint8_t *)stage->ptr;
     if (parquet_trace()) t_staged = now_ms();
-    ahead->done.get();
+    ParquetReadAhead::Progress &pr = *ahead->progress;
+    pr.wait_all_awake();
+    const double t_woken = parquet_trace() ? now_ms() : 0.0;
+    if (pr.err) std::rethrow_exception(pr.err);
+    ctx->bind();
+    QE_HIP(hipStreamWaitEvent(ctx->stream, stage->images, 0));
+    dev = ahead->dev;
+    dev_copied = raw_len;
+    if (parquet_trace())
+      fprintf(stderr,
+              "qe_gpu parquet: column %s: its %zu slices were read and queued in %.3f ms (%.1f GB/s; reading %.3f ms a slice, queueing %.3f, at most %.3f), the last %.3f ms %s its "
+              "turn came; woken %.3f ms after it, stream wait queued in %.3f ms\n",
+              col.name.c_str(), pr.n_slices, pr.last_end - pr.first_start, (double)raw_len / 1e6 / std::max(pr.last_end - pr.first_start, 1e-6),
+              pr.reading / (double)std::max<size_t>(pr.n_slices, 1), pr.queueing / (double)std::max<size_t>(pr.n_slices, 1), pr.longest_queueing, std::abs(pr.last_end - t_staged),
+              pr.last_end < t_staged ? "before" : "after", t_woken - std::max(pr.last_end, t_staged), now_ms() - t_woken);
+    ahead->progress.reset();  // (from here on the device block is this stream's to hand back)
   } else {
     if (cm.codec == CODEC_NONE) {
       // the image is the chunk as it lies in the file: read it straight into pinned memory
@@ -671,10 +748,15 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
   const size_t total = at + 16;
   if (total > stage->cap) {
     // tables did not fit behind the image: this staging buffer grows (nobody else holds it: its last copy was waited
-    // for when it was handed out)
+    // for when it was handed out; copies of this chunk's own slices are waited for here)
     void *bigger = nullptr;
     const size_t cap = total + total / 4;
     ctx->bind();
+    if (dev_copied) {
+      ctx->sync();
+      dev_copied = 0;
+      dev.reset();
+    }
     QE_HIP(hipHostMalloc(&bigger, cap, hipHostMallocDefault));
     memcpy(bigger, image, image_len);
     QE_HIP(hipHostFree(stage->ptr));
@@ -691,8 +773,12 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
 
   if (parquet_trace()) t_walked = now_ms();
   ctx->bind();
-  BufferPtr dev = device_buffer(ctx, total);
-  QE_HIP(hipMemcpyAsync(dev->ptr, st, total, hipMemcpyHostToDevice, ctx->stream));
+  // the image (what of it is not on its way yet) and the tables behind it, in one copy
+  if (!dev || total > dev->bytes) {
+    dev = device_buffer(ctx, total);
+    dev_copied = 0;
+  }
+  QE_HIP(hipMemcpyAsync((uint8_t *)dev->ptr + dev_copied, st + dev_copied, total - dev_copied, hipMemcpyHostToDevice, ctx->stream));
   QE_HIP(hipEventRecord(stage->copied, ctx->stream));
   stage->pending = true;
   const uint8_t *d = (const uint8_t *)dev->ptr;
@@ -799,6 +885,17 @@ Column decode_chunk(Context *ctx, ParquetFile &f, const ParquetColumn &col, cons
 }
 
 }  // namespace
+
+void ParquetReadAhead::Read::settle() {
+  if (!progress) return;
+  progress->wait_all();
+  progress.reset();
+  // never decoded (the scan went another way, or ended early): the copies queued into the block are waited for
+  if (ctx && ctx->copy_stream) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->copy_stream);
+  }
+}
 
 ParquetFile::~ParquetFile() {
   if (fd >= 0) close(fd);
@@ -916,13 +1013,34 @@ std::vector<int> parquet_project(const ParquetFile &file, const std::vector<std:
   return out;
 }
 
-// Chunks in flight ahead of the one being decoded, the current one included.  Each holds a staging buffer of the ring;
-// the ring has as many again, so that the buffer a new read takes is one whose copy to the device was queued three
-// chunks ago and has long finished - the host never waits for it.
-constexpr int READ_AHEAD_DEPTH = Context::STAGING_BUFFERS / 2;
+// Chunks in flight ahead of the one being decoded, the current one included: as many as hold READ_AHEAD_BYTES between them
+// (the readers must not run dry while the scan waits for the device at the end of a row group), at most
+// READ_AHEAD_DEPTH.  Each holds a staging buffer of the ring; the ring has three more, so that the buffer a new read
+// takes is one whose copy to the device was queued at least three chunks ago and has long finished - the host never
+// waits for it.
+constexpr int READ_AHEAD_DEPTH = Context::STAGING_BUFFERS - 3;
+constexpr size_t READ_AHEAD_BYTES = (size_t)192 << 20;
+// (slices of 1 MiB and less at the start of a scan, to get the first bytes to the device sooner, cost more in copies
+// than they gained: 9.2-9.9 ms against 8.85 for the 392 MB file of the benchmark)
+static size_t read_ahead_slice() {
+  static const size_t v = [] {
+    const char *e = getenv("QE_PARQUET_SLICE_KB");
+    const long kb = e ? atol(e) : 4096;
+    return (size_t)std::min<long>(std::max<long>(kb, 64), 65536) << 10;
+  }();
+  return v;
+}
 
-// Starts reading chunk (row_group, column) into the next staging buffer on a thread of its own - for chunks that are
-// stored uncompressed (the file's bytes are the image the device decodes); others are read when their turn comes.
+static size_t read_ahead_copy_slices() {
+  static const size_t v = [] {
+    const char *e = getenv("QE_PARQUET_COPY_SLICES");
+    return (size_t)std::min<long>(std::max<long>(e ? atol(e) : 4, 1), 64);
+  }();
+  return v;
+}
+
+// Starts reading chunk (row_group, column) into the next staging buffer, a job of the pool per slice - for chunks that
+// are stored uncompressed (the file's bytes are the image the device decodes); others are read when their turn comes.
 static void read_ahead_issue(Context *ctx, ParquetFile &file, ParquetReadAhead &ahead, int row_group, int column) {
   ParquetReadAhead::Read r;
   r.row_group = row_group;
@@ -930,12 +1048,76 @@ static void read_ahead_issue(Context *ctx, ParquetFile &file, ParquetReadAhead &
   const ParquetChunkMeta &cm = file.row_groups[(size_t)row_group].chunks[(size_t)column];
   const bool plain = cm.codec == CODEC_NONE && file.columns[(size_t)column].type != 0 && cm.start >= 4 && cm.size >= 0 && cm.start + cm.size <= file.file_size;
   if (plain) {
+    r.ctx = ctx;
     r.stage = &take_staging(ctx, plain_chunk_staging_bytes(cm));
-    uint8_t *dst = (uint8_t *)r.stage->ptr;
-    ParquetFile *f = &file;
+    r.bytes = (size_t)cm.size;
+    r.dev = device_buffer(ctx, plain_chunk_staging_bytes(cm));
+    Context::Staging &st = *r.stage;
+    if (!ctx->copy_stream) QE_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!st.fence) QE_HIP(hipEventCreateWithFlags(&st.fence, hipEventDisableTiming));
+    if (!st.images) QE_HIP(hipEventCreateWithFlags(&st.images, hipEventDisableTiming));
+    // the device block may be one that kernels queued on the context's stream still read (blocks go back to the pool
+    // while the stream is busy with them): the copies into it wait for what that stream holds now
+    QE_HIP(hipEventRecord(st.fence, ctx->stream));
+    QE_HIP(hipStreamWaitEvent(ctx->copy_stream, st.fence, 0));
+    r.progress = std::make_shared<ParquetReadAhead::Progress>();
+    const size_t slice = read_ahead_slice(), len = r.bytes;
+    const size_t n_slices = (len + slice - 1) / slice;
+    r.progress->n_slices = n_slices;
+    uint8_t *dst = (uint8_t *)st.ptr, *dev = (uint8_t *)r.dev->ptr;
+    const ParquetFile *f = &file;  // (outlives the jobs: a Read is not let go of before they are through)
     const int64_t start = cm.start;
-    const size_t len = (size_t)cm.size;
-    r.done = std::async(std::launch::async, [f, start, dst, len] { read_parallel(*f, start, dst, len); });
+    const int device = ctx->device;
+    hipStream_t copy_stream = ctx->copy_stream;
+    hipEvent_t images = st.images;
+    const bool trace = parquet_trace();
+    if (n_slices == 0) QE_HIP(hipEventRecord(images, copy_stream));
+    // slices are what a reader reads at a time, groups of them what travels in one copy (a copy has a fixed cost on
+    // the device's side: 4 MiB copies reached 44 GB/s where 8 MiB ones reached 47-49)
+    const size_t per_group = read_ahead_copy_slices();
+    r.progress->group_landed.assign((n_slices + per_group - 1) / per_group, 0);
+    for (size_t i = 0; i < n_slices; ++i)
+      IoPool::get().submit([pr = r.progress, f, start, dst, dev, len, slice, i, trace, device, copy_stream, images, per_group, n_slices] {
+        const double t0 = trace ? now_ms() : 0.0;
+        double t1 = 0.0;
+        std::exception_ptr err;
+        try {
+          const size_t at = i * slice, n = std::min(slice, len - at);
+          read_exact(*f, start + (int64_t)at, dst + at, n);
+          if (trace) t1 = now_ms();
+          const size_t g = i / per_group, in_group = std::min(per_group, n_slices - g * per_group);
+          bool last_of_group;
+          {
+            std::lock_guard<std::mutex> lk(pr->m);
+            last_of_group = ++pr->group_landed[g] == in_group;
+          }
+          if (last_of_group) {
+            const size_t from = g * per_group * slice, to = std::min(len, from + per_group * slice);
+            QE_HIP(hipSetDevice(device));
+            QE_HIP(hipMemcpyAsync(dev + from, dst + from, to - from, hipMemcpyHostToDevice, copy_stream));
+          }
+        } catch (...) {
+          err = std::current_exception();
+        }
+        std::lock_guard<std::mutex> g(pr->m);
+        if (err && !pr->err) pr->err = err;
+        if (trace) {
+          if (pr->n_landed == 0 || t0 < pr->first_start) pr->first_start = t0;
+          const double t2 = now_ms();
+          pr->last_end = std::max(pr->last_end, t2);
+          if (t1 > 0.0) pr->reading += t1 - t0, pr->queueing += t2 - t1, pr->longest_queueing = std::max(pr->longest_queueing, t2 - t1);
+        }
+        if (++pr->n_landed == pr->n_slices) {
+          // every slice's copy has been queued: the event behind them all
+          try {
+            QE_HIP(hipEventRecord(images, copy_stream));
+          } catch (...) {
+            if (!pr->err) pr->err = std::current_exception();
+          }
+          pr->all_landed.store(true, std::memory_order_release);
+          pr->cv.notify_all();
+        }
+      });
   }
   ahead.queue.push_back(std::move(r));
 }
@@ -969,16 +1151,18 @@ Batch parquet_read_row_group(Context *ctx, ParquetFile &file, int row_group, con
     ParquetReadAhead::Read mine;
     if (ahead) {
       // reads left over from a scan that went another way (a restart) are waited for and dropped
-      while (!ahead->queue.empty() && (ahead->queue.front().row_group != row_group || ahead->queue.front().column != c)) {
-        if (ahead->queue.front().done.valid()) ahead->queue.front().done.wait();
-        ahead->queue.pop_front();
-      }
+      while (!ahead->queue.empty() && (ahead->queue.front().row_group != row_group || ahead->queue.front().column != c)) ahead->queue.pop_front();
       if (ahead->queue.empty()) read_ahead_issue(ctx, file, *ahead, row_group, c);
       // top up: the chunks after the last one queued
       int g = ahead->queue.back().row_group;
       size_t at = 0;
       while (at < columns.size() && columns[at] != ahead->queue.back().column) ++at;
-      while ((int)ahead->queue.size() < READ_AHEAD_DEPTH && at < columns.size() && next_of(g, at)) read_ahead_issue(ctx, file, *ahead, g, columns[at]);
+      size_t in_flight = 0;
+      for (const ParquetReadAhead::Read &r : ahead->queue) in_flight += r.bytes;
+      while ((int)ahead->queue.size() < READ_AHEAD_DEPTH && (ahead->queue.size() < 2 || in_flight < READ_AHEAD_BYTES) && at < columns.size() && next_of(g, at)) {
+        read_ahead_issue(ctx, file, *ahead, g, columns[at]);
+        in_flight += ahead->queue.back().bytes;
+      }
       mine = std::move(ahead->queue.front());
       ahead->queue.pop_front();
     }

@@ -11,4 +11,4 @@ tail -1 $O/fuzz.log
 timeout -k 10 400 python3 -u $R/tools/parquet_probe.py 32000000 3 > $O/probe.log 2>&1 || { tail -20 $O/probe.log; exit 1; }
 grep -v amdgpu.ids $O/probe.log
 QE_PARQUET_TRACE=1 timeout -k 10 400 python3 -u $R/tools/parquet_probe.py 32000000 1 > $O/trace.log 2>&1 || { tail -20 $O/trace.log; exit 1; }
-grep "row group\|column a" $O/trace.log | head -12
+grep "row group\|column a\|column b" $O/trace.log | sed -n "1,24p"

@@ -54,7 +54,18 @@ def main():
               flush=True)
         return out
 
-    timed("scan k,a,b,c", lambda: qe.ParquetScanExec(ctx, path, ["k", "a", "b", "c"]), n * 32)
+    class Streamed:
+        """A consumer that takes a row group at a time and lets go of it."""
+        def __init__(self, plan):
+            self.plan = plan
+
+        def execute(self):
+            for batch in self.plan.execute():
+                del batch
+            return []
+
+    timed("scan k,a,b,c, batches kept", lambda: qe.ParquetScanExec(ctx, path, ["k", "a", "b", "c"]), n * 32)
+    timed("scan k,a,b,c", lambda: Streamed(qe.ParquetScanExec(ctx, path, ["k", "a", "b", "c"])), n * 32)
     timed("scan a", lambda: qe.ParquetScanExec(ctx, path, ["a"]), n * 8)
     timed("scan k", lambda: qe.ParquetScanExec(ctx, path, ["k"]), n * 8)
     timed("scan s", lambda: qe.ParquetScanExec(ctx, path, ["s"]), n * 11)
