@@ -397,3 +397,67 @@ def test_row_group_shards(qe, ctx, tmp_path):
     assert np.allclose(np.asarray(merged[1].values)[om], np.asarray(whole[1].values)[ow], rtol=1e-12)
     assert np.array_equal(np.asarray(merged[2].values)[om], np.asarray(whole[2].values)[ow])
     assert np.allclose(np.asarray(merged[3].values)[om], np.asarray(whole[3].values)[ow], rtol=1e-12)
+
+
+def test_chunks_of_many_slices_and_a_scan_left_early(qe, ctx, tmp_path):
+    """Column chunks that reach the device in several copies of several slices each (26 MB: six 4 MiB slices and a
+    ragged seventh, in two copies), three row groups so that chunks of later row groups are on their way while an
+    earlier one is decoded; a consumer that leaves after the first batch (reads and copies still in flight are waited
+    for when the scan is dropped), then the same file again in full: every value bit for bit what was written, the
+    first row group also against the oracle's decode (data_source.rs:24-72: one chunk per row group, in order)."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    per, groups = 3_300_001, 3
+    n = per * groups - 77  # (the last row group is shorter)
+    rng = np.random.default_rng(23)
+    k = rng.integers(-2 ** 62, 2 ** 62, n)
+    x, y = rng.standard_normal(n), rng.random(n)
+    path = str(tmp_path / "slices.parquet")
+    pq.write_table(pa.table({"k": pa.array(k), "x": pa.array(x), "y": pa.array(y)}), path, compression="none", use_dictionary=False, row_group_size=per)
+    it = iter(qe.ParquetScanExec(ctx, path).execute())
+    first = next(it)
+    assert first.num_rows == per
+    del it  # the scan goes with chunks of the second row group in flight
+    cols = first.columns()
+    assert np.array_equal(np.asarray(cols[0].values), k[:per])
+    ref0 = next(iter(porc.ParquetFile(path).scan()))
+    for c, a in zip(cols, ref0.arrays):
+        column_equals_oracle(c, a)
+    del first, cols
+    for _ in range(2):  # twice: the second scan finds the staging buffers and device blocks of the first
+        at = 0
+        for b in qe.ParquetScanExec(ctx, path).execute():
+            cols = b.columns()
+            m = b.num_rows
+            assert np.array_equal(np.asarray(cols[0].values), k[at:at + m])
+            assert np.array_equal(np.asarray(cols[1].values).view(np.uint64), x[at:at + m].view(np.uint64))
+            assert np.array_equal(np.asarray(cols[2].values).view(np.uint64), y[at:at + m].view(np.uint64))
+            at += m
+        assert at == n
+    # a projection that skips the middle column: the chunks read ahead are the projected ones only
+    at = 0
+    for b in qe.ParquetScanExec(ctx, path, ["k", "y"]).execute():
+        cols = b.columns()
+        assert len(cols) == 2 and np.array_equal(np.asarray(cols[1].values).view(np.uint64), y[at:at + b.num_rows].view(np.uint64))
+        at += b.num_rows
+    assert at == n
+
+
+def test_a_file_cut_short_under_the_readers(qe, ctx, tmp_path):
+    """The file shrinks between the moment its footer is read and the moment its chunks are: the failure of a reader
+    thread (an unexpected end of file) comes back as the scan's IoError, and the context serves the next scan."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    n = 2_000_000
+    rng = np.random.default_rng(29)
+    tbl = pa.table({"a": pa.array(rng.random(n)), "b": pa.array(rng.random(n))})
+    path = str(tmp_path / "shrinks.parquet")
+    pq.write_table(tbl, path, compression="none", use_dictionary=False, row_group_size=n // 2)
+    it = iter(qe.ParquetScanExec(ctx, path).execute())  # (the footer is read here)
+    os.truncate(path, os.path.getsize(path) // 3)       # ends inside the first row group's second chunk
+    with pytest.raises(qe.QeError) as e:
+        list(it)
+    assert e.value.name == "IoError", e.value
+    del it
+    pq.write_table(tbl, path, compression="none", use_dictionary=False, row_group_size=n // 2)
+    assert sum(b.num_rows for b in qe.ParquetScanExec(ctx, path).execute()) == n
