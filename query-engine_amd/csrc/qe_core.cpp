@@ -125,15 +125,15 @@ void batch_settle(Batch &b) {
   std::shared_ptr<PendingRows> p = b.pending;
   p->wait();
   b.pending.reset();
-  if (p->host[2] != 0) fail(QE_ERR_INTERNAL, "filter look-back timed out");
-  const int64_t m = (int64_t)p->host[1];
+  if (p->host[p->filter_at + 2] != 0) fail(QE_ERR_INTERNAL, "filter look-back timed out");
+  const int64_t m = (int64_t)p->host[p->filter_at + 1];
   b.rows = m;
   for (size_t i = 0; i < b.cols.size(); ++i) {
     Column &c = b.cols[i];
     c.length = m;
     const int slot = i < p->utf8_slot.size() ? p->utf8_slot[i] : -1;
     if (c.type == QE_TYPE_UTF8 && slot >= 0) {
-      const unsigned long long *w = p->host + 4 + 4 * slot;
+      const unsigned long long *w = p->host + 4 * slot;
       if (w[2] != 0) fail(QE_ERR_INTERNAL, "string gather look-back timed out");
       c.values_bytes = (int64_t)w[1];
     } else if (c.type == QE_TYPE_BOOLEAN) {

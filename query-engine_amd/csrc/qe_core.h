@@ -128,7 +128,8 @@ struct Column {
 // kernels say how many rows (and, per string column, bytes) there really are.
 struct PendingRows {
   std::shared_ptr<Context> ctx_ref;
-  unsigned long long *host = nullptr;  // [0..2] the filter's ticket / rows / look-back error, then four words per string column (ticket, bytes, error, -)
+  unsigned long long *host = nullptr;  // four words per string column (ticket, bytes, error, -), then at `filter_at` the filter's ticket / rows / look-back error
+  int filter_at = 0;
   hipEvent_t ready = nullptr;          // recorded behind the last copy into `host`
   std::vector<int> utf8_slot;          // per output column: its block of four words, or -1
   bool waited = false;

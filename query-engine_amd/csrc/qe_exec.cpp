@@ -141,8 +141,19 @@ static Column utf8_broadcast_column(Context *ctx, const std::string &s, int64_t 
 // With `pending` the host does not wait at all: `m` is then only a bound (the batch's rows), the kernels read the
 // number of rows from `m_dev` (the word the filter kernel left it in), every output is sized for the bound - the bytes by
 // the source column's - and the byte totals travel to the pending batch's pinned words (from block `first_slot` on).
+// A block the caller has cleared with one fill and that holds what a deferred selection's kernels need zeroed: every
+// string column's control block (in column order, the filter's own scratch right behind them, so that one copy takes
+// all result words to the host), their status arrays and their validity bitmaps.  Without it the gather takes and
+// clears blocks of its own - a fill and a copy are a small launch each, one after the other on the stream, and a
+// selection of ten string columns made six of them a batch.
+struct GatherArena {
+  BufferPtr block;
+  size_t control_at = 0, status_at = 0, bitmaps_at = 0;
+};
+
 static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<const Column *> &srcs, const int32_t *idx, int64_t m,
-                                               const unsigned long long *m_dev = nullptr, PendingRows *pending = nullptr, int first_slot = 0) {
+                                               const unsigned long long *m_dev = nullptr, PendingRows *pending = nullptr, int first_slot = 0,
+                                               const GatherArena *arena = nullptr) {
   // a column's control block: ticket, byte total, look-back error, one word of padding - the head of a FilterScratch,
   // of which the offsets kernel touches nothing else
   constexpr size_t GROUP = UTF8_GATHER_MAX_COLS, FIRST_WORD = 64, CONTROL_WORDS = 4, CONTROL_BYTES = CONTROL_WORDS * sizeof(unsigned long long);
@@ -153,7 +164,7 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
   for (size_t g0 = 0; g0 < srcs.size(); g0 += GROUP) {
     const size_t g1 = std::min(srcs.size(), g0 + GROUP), cols = g1 - g0;
     BufferPtr scratch;  // the group's control blocks, then its status arrays
-    if (m > 0) {
+    if (m > 0 && !arena) {
       const size_t sb = (cols * CONTROL_BYTES + 63) / 64 * 64 + cols * status_bytes + sizeof(FilterScratch);
       scratch = device_buffer(ctx, sb);
       QE_HIP(hipMemsetAsync(scratch->ptr, 0, sb, ctx->stream));
@@ -166,7 +177,12 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
     size_t nullable = 0;
     for (size_t j = g0; j < g1; ++j) nullable += srcs[j]->validity ? 1 : 0;
     BufferPtr bitmaps;
-    if (nullable) {
+    size_t bitmaps_at = 0;
+    if (nullable && arena) {
+      bitmaps = arena->block;
+      bitmaps_at = arena->bitmaps_at;
+      for (size_t j = 0; j < g0; ++j) bitmaps_at += srcs[j]->validity ? bb : 0;
+    } else if (nullable) {
       bitmaps = device_buffer(ctx, nullable * bb);
       QE_HIP(hipMemsetAsync(bitmaps->ptr, 0, nullable * bb, ctx->stream));
     }
@@ -179,7 +195,7 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
       c.length = m;
       c.offsets = device_buffer(ctx, (size_t)(m + 1) * 4 + 16);
       if (src.validity) {
-        c.validity = sub_buffer(bitmaps, next_bitmap++ * bb, bb);
+        c.validity = sub_buffer(bitmaps, bitmaps_at + next_bitmap++ * bb, bb);
         c.null_count = -1;
       }
       if (m <= 0) {
@@ -194,8 +210,13 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
       g.src_total = src.values ? (int64_t)std::max<size_t>(src.values->bytes, (size_t)std::max<int64_t>(src.values_bytes, 0)) : 0;
       g.out_offsets = (int32_t *)c.offsets->ptr;
       g.out_validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
-      g.control = (char *)scratch->ptr + (j - g0) * CONTROL_BYTES;
-      g.status = (char *)scratch->ptr + (cols * CONTROL_BYTES + 63) / 64 * 64 + (j - g0) * status_bytes;
+      if (arena) {
+        g.control = (char *)arena->block->ptr + arena->control_at + j * CONTROL_BYTES;
+        g.status = (char *)arena->block->ptr + arena->status_at + j * status_bytes;
+      } else {
+        g.control = (char *)scratch->ptr + (j - g0) * CONTROL_BYTES;
+        g.status = (char *)scratch->ptr + (cols * CONTROL_BYTES + 63) / 64 * 64 + (j - g0) * status_bytes;
+      }
       if (pending) {
         // no selection keeps more bytes than the column has
         c.values_bytes = std::max<int64_t>(src.values_bytes, 0);
@@ -209,7 +230,8 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
       ctx->prof_begin("qe_utf8_gather_fused_kernel");
       QE_HIP(launch_utf8_gather_fused(launch, idx, m, m_dev, ctx->dev.cus, ctx->stream));
       ctx->prof_end();
-      QE_HIP(hipMemcpyAsync(pending->host + 4 + CONTROL_WORDS * (first_slot + g0), scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+      // (with an arena the caller copies every column's words, and the filter's, in one go)
+      if (!arena) QE_HIP(hipMemcpyAsync(pending->host + CONTROL_WORDS * (first_slot + g0), scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
       continue;
     }
     // lengths by row id, scanned into offsets, in one pass over all columns of the group; offs[m] = a column's byte total
@@ -217,7 +239,7 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
     QE_HIP(launch_utf8_gather_offsets(launch, idx, m, m_dev, ctx->dev.cus, ctx->stream));
     ctx->prof_end();
     if (pending) {
-      QE_HIP(hipMemcpyAsync(pending->host + 4 + CONTROL_WORDS * (first_slot + g0), scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+      if (!arena) QE_HIP(hipMemcpyAsync(pending->host + CONTROL_WORDS * (first_slot + g0), scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
     } else {
       QE_HIP(hipMemcpyAsync(ctx->host_counters + FIRST_WORD, scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
       ctx->sync();  // (the scratch block is done with here too)
@@ -538,18 +560,10 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
       vm_list.push_back((int)i);
     }
   }
-  ensure_filter_scratch(ctx, n);
   ensure_counters(ctx);
-  FilterScratch *scratch = (FilterScratch *)ctx->filter_scratch;
-  // the validity bitmaps of all nullable outputs in one block, cleared by one fill
   const size_t out_bb = bitmap_bytes(n);
   size_t nullable_outs = 0, next_bitmap = 0;
   for (int i : vm_list) nullable_outs += expr_nullable(outs[i], schema) ? 1 : 0;
-  BufferPtr out_bitmaps;
-  if (nullable_outs > 1) {
-    out_bitmaps = device_buffer(ctx, nullable_outs * out_bb);
-    QE_HIP(hipMemsetAsync(out_bitmaps->ptr, 0, nullable_outs * out_bb, ctx->stream));
-  }
   int64_t m = 0;
   Column rowid;
   bool need_rowid = !utf8_cols.empty();
@@ -560,13 +574,52 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
   // literals as outputs (their broadcast is sized by it), more string columns than the pinned block has room for,
   // more outputs than one filter launch takes.
   std::shared_ptr<PendingRows> pending;
-  if ((ctx->flags & QE_FLAG_DEFERRED_ROW_COUNT) && n > 0 && utf8_lits.empty() && 4 + 4 * utf8_cols.size() <= (size_t)Context::PENDING_WORDS) {
+  if ((ctx->flags & QE_FLAG_DEFERRED_ROW_COUNT) && n > 0 && utf8_lits.empty() && 8 + 4 * utf8_cols.size() <= (size_t)Context::PENDING_WORDS) {
     pending = std::make_shared<PendingRows>();
     pending->ctx_ref = ctx->shared_from_this();
     pending->host = ctx->take_pending_words();
     pending->ready = ctx->take_pending_event();
     pending->utf8_slot.assign(outs.size(), -1);
+    pending->filter_at = 4 * (int)utf8_cols.size();
   }
+  // Everything the kernels of a deferred selection need zeroed, in one block under one fill: the string columns' control
+  // blocks, the filter's scratch right behind them, the fixed-width outputs' validity bitmaps, the string columns'
+  // status arrays and bitmaps.
+  GatherArena arena;
+  size_t arena_scratch_at = 0, arena_out_bitmaps_at = 0;
+  FilterScratch *scratch;
+  BufferPtr out_bitmaps;
+  size_t out_bitmaps_at = 0;
+  if (pending) {
+    auto up64 = [](size_t v) { return (v + 63) / 64 * 64; };
+    const size_t n_u = utf8_cols.size();
+    const size_t control = up64(n_u * 32);
+    arena.control_at = control - n_u * 32;  // (the last control block ends where the filter's scratch begins)
+    arena_scratch_at = control;
+    arena_out_bitmaps_at = arena_scratch_at + up64(filter_scratch_bytes(n));
+    arena.status_at = arena_out_bitmaps_at + up64(nullable_outs * out_bb);
+    const size_t status_bytes = n_u ? (utf8_gather_offsets_status_bytes(n) + 63) / 64 * 64 : 0;
+    arena.bitmaps_at = arena.status_at + n_u * status_bytes + sizeof(FilterScratch);
+    size_t nullable_strings = 0;
+    for (int i : utf8_cols) nullable_strings += in.cols[outs[i]->index].validity ? 1 : 0;
+    const size_t total = arena.bitmaps_at + up64(nullable_strings * out_bb);
+    arena.block = device_buffer(ctx, total);
+    QE_HIP(hipMemsetAsync(arena.block->ptr, 0, total, ctx->stream));
+    scratch = (FilterScratch *)((char *)arena.block->ptr + arena_scratch_at);
+    if (nullable_outs) {
+      out_bitmaps = arena.block;
+      out_bitmaps_at = arena_out_bitmaps_at;
+    }
+  } else {
+    ensure_filter_scratch(ctx, n);
+    scratch = (FilterScratch *)ctx->filter_scratch;
+    // the validity bitmaps of all nullable outputs in one block, cleared by one fill
+    if (nullable_outs > 1) {
+      out_bitmaps = device_buffer(ctx, nullable_outs * out_bb);
+      QE_HIP(hipMemsetAsync(out_bitmaps->ptr, 0, nullable_outs * out_bb, ctx->stream));
+    }
+  }
+  const bool scratch_cleared = pending != nullptr;  // (the first pass finds it zeroed)
   while (first || k < vm_list.size()) {
     Compiler comp(ctx, &in);
     FilterArgs args{};
@@ -578,7 +631,7 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
     }
     k = lower_filter(comp, schema, pred, outs, types, vm_list, k, n, rowid_values, args, [&](int i, bool nullable, VmOut &o) {
       Column c = make_fixed_column(ctx, types[i], n, nullable, false,
-                                   nullable && out_bitmaps && next_bitmap < nullable_outs ? sub_buffer(out_bitmaps, next_bitmap++ * out_bb, out_bb) : nullptr);
+                                   nullable && out_bitmaps && next_bitmap < nullable_outs ? sub_buffer(out_bitmaps, out_bitmaps_at + next_bitmap++ * out_bb, out_bb) : nullptr);
       o.values = c.values->ptr;
       o.validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
       out.cols[i] = c;
@@ -587,7 +640,7 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
     // (outputs that take more than one pass: every pass's result words are checked against the first's on the host)
     if (pending && k < vm_list.size()) pending.reset();
     args.scratch = scratch;
-    QE_HIP(launch_filter_reset(scratch, n, ctx->stream));
+    if (!(first && scratch_cleared)) QE_HIP(launch_filter_reset(scratch, n, ctx->stream));
     const char *kname = "qe_filter_kernel";
     ctx->prof_begin(kname, n);
     QE_HIP(launch_filter(args, ctx->dev, ctx->stream, &kname));
@@ -606,8 +659,6 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
     first = false;
   }
   if (pending) {
-    // the filter's result words now; the string columns' byte totals follow from the gather below
-    QE_HIP(hipMemcpyAsync(pending->host, scratch, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     out.rows = n;
     for (int i : vm_list) finish_fixed_column(out.cols[i], n);
     if (!utf8_cols.empty()) {
@@ -616,9 +667,12 @@ static Batch run_pipeline_typed(Context *ctx, const Batch &in_raw, const std::ve
         srcs.push_back(&in.cols[outs[utf8_cols[j]]->index]);
         pending->utf8_slot[utf8_cols[j]] = (int)j;
       }
-      std::vector<Column> got = utf8_gather_columns(ctx, srcs, (const int32_t *)rowid.values->ptr, n, &scratch->total, pending.get(), 0);
+      std::vector<Column> got = utf8_gather_columns(ctx, srcs, (const int32_t *)rowid.values->ptr, n, &scratch->total, pending.get(), 0, &arena);
       for (size_t j = 0; j < utf8_cols.size(); ++j) out.cols[utf8_cols[j]] = std::move(got[j]);
     }
+    // the string columns' control blocks and, behind them, the filter's result words: one copy
+    QE_HIP(hipMemcpyAsync(pending->host, (char *)arena.block->ptr + arena.control_at, (4 * utf8_cols.size() + 3) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                          ctx->stream));
     QE_HIP(hipEventRecord(pending->ready, ctx->stream));
     out.pending = pending;
     return out;
