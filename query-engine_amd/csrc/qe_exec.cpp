@@ -1396,11 +1396,14 @@ struct AggState {
       g.n_accs = args.n_accs;
       g.slots = std::max(1, std::min(expected_batches > 0 ? expected_batches : 4, 8));
       const size_t cells = spill_cells(g.bits, g.blocks * g.slots);
-      g.cell_buf = device_buffer(ctx, (cells + 1) * 4 + 64);
+      // the cell table (a slot no launch fills holds no rows), the group's control words and, for the first pass that
+      // partitions directly, its overflow word: one block under one fill
+      const size_t cell_bytes = ((cells + 1) * 4 + 255) & ~(size_t)255;
+      g.cell_buf = device_buffer(ctx, cell_bytes + 512);
       g.scan_buf = device_buffer(ctx, scan_scratch_elems((int64_t)cells) * 4 + 64);
-      g.ctrl = device_buffer(ctx, 256);
-      QE_HIP(hipMemsetAsync(g.cell_buf->ptr, 0, (cells + 1) * 4, ctx->stream));  // (a slot no launch fills holds no rows)
-      QE_HIP(hipMemsetAsync(g.ctrl->ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
+      g.ctrl = sub_buffer(g.cell_buf, cell_bytes, 256);
+      QE_HIP(hipMemsetAsync(g.cell_buf->ptr, 0, cell_bytes + 512, ctx->stream));
+      if (sp.direct && !direct_overflow) direct_overflow = sub_buffer(g.cell_buf, cell_bytes + 256, 256);
       g.log_rows = 0;
     }
     if (sp.direct) {
@@ -2119,16 +2122,23 @@ struct AggState {
     fa.n_outs = (int)spec.outs.size();
     result = Batch();
     result.ctx = ctx;
+    // the nullable outputs' bitmaps and the counter the kernel draws output positions from: one block, one fill (a fill
+    // per column is a small launch each, one after the other on the stream)
+    const size_t out_bb = (bitmap_bytes(capacity) + 63) / 64 * 64;
+    size_t nullable_outs = 0, next_bitmap = 0;
+    for (auto &f : spec.outs) nullable_outs += f.null_mode != NULL_NEVER ? 1 : 0;
+    BufferPtr zeroed = device_buffer(ctx, 64 + nullable_outs * out_bb);
+    QE_HIP(hipMemsetAsync(zeroed->ptr, 0, 64 + nullable_outs * out_bb, ctx->stream));
     for (size_t i = 0; i < spec.outs.size(); ++i) {
       FinOut f = spec.outs[i];
-      Column c = make_fixed_column(ctx, f.type, capacity, f.null_mode != NULL_NEVER, false);
+      const bool nullable = f.null_mode != NULL_NEVER;
+      Column c = make_fixed_column(ctx, f.type, capacity, nullable, false, nullable ? sub_buffer(zeroed, 64 + next_bitmap++ * out_bb, bitmap_bytes(capacity)) : nullptr);
       f.values = c.values->ptr;
       f.validity = c.validity ? (uint32_t *)c.validity->ptr : nullptr;
       fa.outs[i] = f;
       result.cols.push_back(c);
     }
-    QE_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
-    fa.out_count = ctx->counters;
+    fa.out_count = (unsigned long long *)zeroed->ptr;
     ctx->prof_begin("qe_finalize_kernel");
     QE_HIP(launch_finalize(fa, ctx->stream));
     ctx->prof_end();
@@ -2734,7 +2744,10 @@ qe_status qe_batch_column(const qe_batch *batch, int32_t index, qe_column *out) 
     Column &c = settled(batch).cols[index];
     if (c.null_count < 0) {
       // output bitmaps are produced by whole-word stores / atomics into padded buffers: count on demand
-      bool word_ok = c.space == QE_MEM_HOST || c.validity->owned;
+      // (a slice of one of this library's own blocks is padded like a block of its own; a borrowed bitmap may end mid-word)
+      const Buffer *root = c.validity.get();
+      while (root->parent) root = root->parent.get();
+      bool word_ok = c.space == QE_MEM_HOST || root->owned;
       if (word_ok) c.null_count = count_nulls(batch->b.ctx, c);
     }
     out->type = c.type;
