@@ -279,7 +279,10 @@ def main():
     C = qe.ColumnExpression
     mode = qe.AGG_MODE_PARTIAL if multi else qe.AGG_MODE_SINGLE
     aggs = lambda col: [qe.SumExpression(C(col)), qe.CountExpression(None)]
-    hint = max(64, 2 * args.groups)
+    # (the expected number of groups: twice the few-groups case's handful; a tenth above a large count, as the
+    # single-GPU configuration over a million keys hints it - the many-groups mode sizes its partitions by the hint,
+    # and 512 partitions, what its fastest passes take, hold 1.3 M groups of this shape)
+    hint = max(64, 2 * args.groups) if args.groups <= 65536 else args.groups + args.groups // 10
 
     def local_plan():
         scan = qe.ScanExec(ctx, batches)

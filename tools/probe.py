@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small single-GPU driver for profiling one configuration under rocprofv3.
 
-usage: probe.py <c2|c3|c5|c4|c5m|p|utf8> [rows] [reps] [batches]   (the rows in that many equal batches, default 1; c5m: the c5 plan over 1 M uniform keys; utf8: the reference's
+usage: probe.py <c2|c3|c5|c4|c5m|c5mp|p|utf8> [rows] [reps] [batches]   (the rows in that many equal batches, default 1; c5m: the c5 plan over 1 M uniform keys; utf8: the reference's
 test_filter shape at 100 M rows, bench.py's utf8_filter_config, with the deferred row count)
 """
 import importlib
@@ -37,7 +37,7 @@ def main():
     c = torch.empty(n, dtype=torch.float64, device=dev)
     if cfg == "c4":
         ctx.generate(2, 77, 0, n, 1_000_000, 1.1, k.data_ptr())
-    elif cfg == "c5m":
+    elif cfg in ("c5m", "c5mp"):
         ctx.generate(1, 99, 0, n, 0, 1_000_000, k.data_ptr())
     else:
         ctx.generate(3, 43, 0, n, 0, 0, k.data_ptr())
@@ -63,6 +63,8 @@ def main():
             return qe.ProjectionExec([scan], [qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
         sel = qe.SelectionExec([scan], qe.GtExpression(C(3), qe.LiteralFloatExpression(0.5)))
         proj = qe.ProjectionExec([sel], [C(0), qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
+        if cfg == "c5mp":  # a rank's share of the plan over a million keys: a PARTIAL aggregate, hinted as bench.py hints it
+            return qe.AggregateExec([proj], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None)], mode=qe.AGG_MODE_PARTIAL, group_capacity_hint=int(os.environ.get("QE_PROBE_HINT", "1100000")))
         return qe.AggregateExec([proj], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None)],
                                 group_capacity_hint=1_100_000 if cfg == "c5m" else 64)
 
