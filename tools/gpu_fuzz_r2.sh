@@ -1,5 +1,5 @@
 #!/bin/bash
-# Seeded fuzzers against the oracle with this round's options switched on: order-independent sums (aggregations, the
+# Seeded fuzzers against the oracle with the newer options switched on: order-independent sums (aggregations, the
 # PARTIAL / FINAL / deferred modes), string plans with the run-time compiler.  Progress goes to gpurun_out/fuzz/.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}

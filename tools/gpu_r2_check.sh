@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 GPU-box check: the no-alloc entry point's test alone, then the whole GPU suite, then the bench with the
+# Check: the no-alloc entry point's test alone, then the whole GPU suite, then the bench with the
 # rocprofv3 kernel summary of the same command taken in the same session.  Every GPU step has its own time limit.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}

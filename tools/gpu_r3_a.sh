@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 GPU-box check A: the tests this round added or changed, each file under a time limit of its own.
+# Check A: the tests added or changed last, each file under a time limit of its own.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r3a

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 GPU-box check B: the order-independent sums' tests, the whole GPU suite, then the default bench line.
+# Check B: the order-independent sums' tests, the whole GPU suite, then the default bench line.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r3b

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 GPU-box check C: the deferred row count's tests, then the selection tests of the parity suite (unchanged paths).
+# Check C: the deferred row count's tests, then the selection tests of the parity suite (unchanged paths).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r3c

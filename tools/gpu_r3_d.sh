@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 GPU-box check D: hashed group keys' equality check, then every test that groups by strings or tuples.
+# Check D: hashed group keys' equality check, then every test that groups by strings or tuples.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r3d

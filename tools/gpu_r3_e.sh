@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 experiment E: one scatter level against two (C4 and the C5 plan over 1 M uniform keys), then a bench line.
+# Experiment E: one scatter level against two (C4 and the C5 plan over 1 M uniform keys), then a bench line.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r3e

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 check F: the many-groups path's parity tests, then its probes with the one-pass scatter on and off.
+# Check F: the many-groups path's parity tests, then its probes with the one-pass scatter on and off.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r3f

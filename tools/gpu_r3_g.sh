@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 check G: many-groups parity tests, then probes with one environment setting against the default (A/B on one box).
+# Check G: many-groups parity tests, then probes with one environment setting against the default (A/B on one box).
 # usage: gpu_r3_g.sh VAR=value [cfgs...]
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}

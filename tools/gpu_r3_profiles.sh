@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence, one session: the default bench line; rocprofv3 kernel summaries of the headline, of C4, of the C5 plan
+# Evidence, one session: the default bench line; rocprofv3 kernel summaries of the headline, of C4, of the C5 plan
 # over a million uniform keys and of the string shape, each next to the line the profiled process printed; PMC passes
 # (one run each) on C4's kernels and on the string gather's.  Everything lands in gpurun_out/r3p.
 set -o pipefail
