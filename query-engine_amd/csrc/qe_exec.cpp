@@ -1064,6 +1064,11 @@ static int spill_partition_bits(int n_accs, int64_t group_hint) {
     return e ? atoi(e) : 0;
   }();
   if (forced_bits >= 1 && forced_bits <= 11 && forced_bits >= bits) bits = forced_bits;
+  static int bits_cap = [] {
+    const char *e = getenv("QE_SPILL_BITS_CAP");  // (experiments: fewer partitions than the hint asks for; what does not fit a partition's table goes to the global one row by row)
+    return e ? atoi(e) : 0;
+  }();
+  if (bits_cap >= 8 && bits > bits_cap) bits = bits_cap;
   return bits;
 }
 

@@ -38,7 +38,7 @@ def main():
     if cfg == "c4":
         ctx.generate(2, 77, 0, n, 1_000_000, 1.1, k.data_ptr())
     elif cfg in ("c5m", "c5mp"):
-        ctx.generate(1, 99, 0, n, 0, 1_000_000, k.data_ptr())
+        ctx.generate(1, 99, 0, n, 0, int(os.environ.get("QE_PROBE_KEYS", "1000000")), k.data_ptr())
     else:
         ctx.generate(3, 43, 0, n, 0, 0, k.data_ptr())
     ctx.generate(0, 44, 0, n, -1.0, 1.0, a.data_ptr())
@@ -66,7 +66,7 @@ def main():
         if cfg == "c5mp":  # a rank's share of the plan over a million keys: a PARTIAL aggregate, hinted as bench.py hints it
             return qe.AggregateExec([proj], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None)], mode=qe.AGG_MODE_PARTIAL, group_capacity_hint=int(os.environ.get("QE_PROBE_HINT", "1100000")))
         return qe.AggregateExec([proj], [C(0)], [qe.SumExpression(C(1)), qe.CountExpression(None)],
-                                group_capacity_hint=1_100_000 if cfg == "c5m" else 64)
+                                group_capacity_hint=int(os.environ.get("QE_PROBE_HINT", "1100000")) if cfg == "c5m" else 64)
 
     def run():
         try:
