@@ -1022,6 +1022,7 @@ struct SpillPlan {
   uint8_t acc_col[VM_MAX_ACCS];
   // the partition passes: hash bits that name a partition, workgroups, the cell tables [partition][workgroup]
   int bits = 0, blocks = 0;
+  int sub_bits = 0;  // further hash bits by which the partition-wise aggregate folds a partition in several passes (PartArgs::sub_bits)
   BufferPtr cell_buf, cell1_buf, scan_buf;
   bool counted = false;  // the first pass filled the cell table and the log's length itself
   // The log can wait for the logs of the batches that follow and be partitioned and aggregated together with them
@@ -1038,7 +1039,7 @@ struct SpillPlan {
 // one wait, one scatter per log into one partitioned copy and one partition-wise aggregate follow when the group is
 // full or the result is asked for.
 struct SpillGroup {
-  int bits = 0, blocks = 0, slots = 0, n_accs = 0;
+  int bits = 0, sub_bits = 0, blocks = 0, slots = 0, n_accs = 0;
   BufferPtr cell_buf, scan_buf, ctrl;  // ctrl: [0] rows logged by the group's launches, [1] the partition ticket, [2] rows they selected, [3] rows partitioned directly
   struct Item {
     BufferPtr keys, vals, counts;
@@ -1150,6 +1151,17 @@ static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &b
     return e ? atoi(e) : 0;
   }();
   sp.bits = spill_partition_bits(args.n_accs, group_hint);
+  // More groups than 512 partitions' tables hold: still 512 partitions - what the one-pass scatter, the first pass that
+  // partitions directly and the grouped logs take - each folded in two or four passes over its rows by the next hash
+  // bits.  (1024 partitions meant two scatter levels batch by batch: 2 M uniform keys, 500 M rows, 10.5 ms.)
+  static const bool sub_passes = [] {
+    const char *e = getenv("QE_SPILL_SUB_PASSES");
+    return e ? atoi(e) != 0 : true;
+  }();
+  if (sub_passes && sp.bits > 9) {
+    sp.sub_bits = sp.bits - 9;
+    sp.bits = 9;
+  }
   sp.blocks = forced_blocks > 0 ? forced_blocks : ctx->dev.cus;
   if (want_direct && may_group && a.pairs && args.block_threads == (uint32_t)AGG_WIDE_THREADS && grid == sp.blocks && sp.blocks == ctx->dev.cus &&
       (args.tune & 2u) && sp.blocks * PART_MAX_DIRECT <= PART_MAX_DIRECT_UNITS && aggregate_direct_available(args, ctx->dev, sp.bits)) {
@@ -1281,6 +1293,8 @@ static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &
   pa.table = args.table;
   pa.lds_cap = partitioned_lds_slots(args.n_accs);
   pa.lds_limit = pa.lds_cap - pa.lds_cap / 4;
+  pa.part_bits = bits;
+  pa.sub_bits = sp.sub_bits;
   pa.ticket = total + 1;
   ctx->prof_begin("qe_aggregate_partitioned_kernel");
   QE_HIP(launch_aggregate_partitioned(pa, ctx->dev, ctx->stream));
@@ -1392,11 +1406,12 @@ struct AggState {
 
   void spill_attach(SpillPlan &sp, AggArgs &args) {
     SpillGroup &g = spill_group;
-    if (!g.items.empty() && (g.bits != sp.bits || g.blocks != sp.blocks || g.n_accs != args.n_accs || (int)g.items.size() >= g.slots ||
+    if (!g.items.empty() && (g.bits != sp.bits || g.sub_bits != sp.sub_bits || g.blocks != sp.blocks || g.n_accs != args.n_accs || (int)g.items.size() >= g.slots ||
                              g.log_rows + args.spill.capacity >= (1ull << 31)))
       spill_flush();
     if (g.items.empty()) {
       g.bits = sp.bits;
+      g.sub_bits = sp.sub_bits;
       g.blocks = sp.blocks;
       g.n_accs = args.n_accs;
       g.slots = std::max(1, std::min(expected_batches > 0 ? expected_batches : 4, 8));
@@ -1497,6 +1512,8 @@ struct AggState {
       pa.table = g.table;
       pa.lds_cap = partitioned_lds_slots(g.n_accs);
       pa.lds_limit = pa.lds_cap - pa.lds_cap / 4;
+      pa.part_bits = g.bits;
+      pa.sub_bits = g.sub_bits;
       pa.ticket = total + 1;
       pa.direct_blocks = g.blocks;
       for (auto &it : g.items)

@@ -674,10 +674,12 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
       s_ticket = atomicAdd(A.ticket, 1ull);
       s_unit = 0;
       // a global table that has been given up (the host starts over with a larger one): no further partition
-      if (__hip_atomic_load(&A.table.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) s_ticket = (unsigned long long)A.n_parts;
+      if (__hip_atomic_load(&A.table.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) s_ticket = (unsigned long long)A.n_parts << A.sub_bits;
     }
     __syncthreads();
-    const int64_t p = (int64_t)s_ticket;
+    // (a partition's passes hold consecutive tickets: its rows are still in the caches when the next pass reads them)
+    const int64_t p = (int64_t)(s_ticket >> A.sub_bits);
+    const uint32_t sub = (uint32_t)s_ticket & ((1u << A.sub_bits) - 1u);
     if (p < A.n_parts)
       for (uint32_t t = threadIdx.x; t < direct_units; t += blockDim.x) {
         const PartDirect &d = A.direct[t / (uint32_t)A.direct_blocks];
@@ -768,6 +770,11 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
         in.v[j] = nval[j];
         G.slot[j] = SLOT_NONE;
         if (nxt.pos + j * 64 + lane < nxt.end) active |= 1u << j;
+      }
+      if (A.sub_bits) {  // (uniform) the rows of this pass only
+#pragma unroll
+        for (int j = 0; j < VM_R; ++j)
+          if (((hash32(G.key[j]) >> (32 - A.part_bits - A.sub_bits)) & ((1u << A.sub_bits) - 1u)) != sub) active &= ~(1u << j);
       }
       nxt.pos += VM_WAVE_ROWS;
       if (nxt.pos >= nxt.end) have = next_unit(nxt);

@@ -324,6 +324,9 @@ struct PartArgs {
   int32_t n_direct;
   int32_t direct_blocks;           // workgroups of those first passes = stretches per partition and source
   PartDirect direct[PART_MAX_DIRECT];
+  // More groups than n_parts tables hold: a partition is folded in 1 << sub_bits passes over its rows, each keeping
+  // the rows whose next sub_bits hash bits (below the part_bits that name the partition) are the pass's number.
+  int32_t part_bits, sub_bits;
 };
 
 constexpr int FIX_FRACTION_BITS = 96;  // fixed-point digits below 2^S

@@ -168,3 +168,57 @@ def test_streaming_protocol_and_partial_final(qe, torch_ctx):
     assert np.array_equal(streamed[0], merged[0]) and np.array_equal(streamed[2], merged[2])
     mag = np.abs(streamed[1]) + 1.0
     assert (np.abs(streamed[1] - merged[1]) <= 1e-9 * mag).all()
+
+
+@pytest.mark.parametrize("n_keys,skewed", [(2_400_000, False), (5_000_000, False), (2_400_000, True)])
+def test_more_groups_than_the_partitions_tables_hold(qe, torch_ctx, n_keys, skewed):
+    """Hints beyond what 512 partitions' LDS tables hold (1.3 M groups of this shape): the partitions stay 512 and each
+    is folded in two or four passes by further hash bits - after the first pass that partitions directly (uniform
+    keys) and after the one with a table and a log (zipf keys), over two batches.  Against torch, as above."""
+    torch, ctx = torch_ctx
+    n = 64_000_003
+    dev = torch.device("cuda", 0)
+    k = torch.empty(n, dtype=torch.int64, device=dev)
+    a, b, c = (torch.empty(n, dtype=torch.float64, device=dev) for _ in range(3))
+    if skewed:
+        ctx.generate(2, 177, 0, n, n_keys, 1.1, k.data_ptr())
+    else:
+        ctx.generate(1, 199, 0, n, 0, n_keys, k.data_ptr())
+    ctx.generate(0, 144, 0, n, -1.0, 1.0, a.data_ptr())
+    ctx.generate(0, 145, 0, n, -1.0, 1.0, b.data_ptr())
+    ctx.generate(0, 146, 0, n, 0.0, 1.0, c.data_ptr())
+    ctx.synchronize()
+    half = n // 2 + 7
+    batches = [qe.Batch.from_torch(ctx, [t[s:e] for t in (k, a, b, c)]) for s, e in ((0, half), (half, n))]
+    C = qe.ColumnExpression
+    aggs = [qe.SumExpression(C(1)), qe.CountExpression(None), qe.AvgExpression(C(1)), qe.MinExpression(C(1)), qe.MaxExpression(C(1))]
+    ctx.profile(True)
+    got = by_key(list(headline_plan(qe, ctx, batches, aggs, hint=n_keys + n_keys // 10).execute())[0].columns())
+    names = kernels_of(ctx)
+    ctx.profile(False)
+    assert any(name.startswith("qe_aggregate_partitioned") for name in names), names
+    assert any(name.startswith("qe_aggregate_spill" if skewed else "qe_aggregate_direct") for name in names), names
+    assert not any("level" in name for name in names), names  # (no two-level scatter: 512 partitions)
+    v, keep = a + b * c, c > 0.5
+    if not skewed:
+        check_against_torch(torch, k, v, keep, got, True)
+        return
+    # Zipf keys: torch's scatter_add_ / scatter_reduce_ take a minute apiece over a key that holds a tenth of the rows
+    # (atomics on one address).  Counts from torch.unique, sums by numpy's bincount on the host (one pass, in row order),
+    # minima and maxima by sorting: values ascending, then a stable sort by key - a group's first row is its minimum,
+    # its last its maximum.
+    uk, inv, cnt = torch.unique(k[keep], return_inverse=True, return_counts=True)
+    assert np.array_equal(got[0], uk.cpu().numpy()) and np.array_equal(got[2], cnt.cpu().numpy())
+    inv_h, v_h = inv.cpu().numpy(), v[keep].cpu().numpy()
+    ref_sum = np.bincount(inv_h, weights=v_h, minlength=len(got[0]))
+    ref_mag = np.bincount(inv_h, weights=np.abs(v_h), minlength=len(got[0]))
+    assert (np.abs(got[1] - ref_sum) <= 2 * REL * ref_mag).all()
+    assert (np.abs(got[3] - ref_sum / got[2]) <= 2 * REL * ref_mag / got[2]).all()
+    vv, order = torch.sort(v[keep], stable=True)
+    kk, order2 = torch.sort(k[keep][order], stable=True)
+    vv = vv[order2]
+    first = torch.ones_like(kk, dtype=torch.bool)
+    first[1:] = kk[1:] != kk[:-1]
+    last = torch.ones_like(first)
+    last[:-1] = first[1:]
+    assert np.array_equal(got[4], vv[first].cpu().numpy()) and np.array_equal(got[5], vv[last].cpu().numpy())
