@@ -187,6 +187,13 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
       QE_HIP(hipMemsetAsync(bitmaps->ptr, 0, nullable * bb, ctx->stream));
     }
     size_t next_bitmap = 0;
+    // Offsets and bytes in one kernel when the output bytes' buffers can be had before their sizes are known: always for
+    // a selection that does not wait (they are sized by the source's bytes), and for one that does when it keeps a
+    // quarter of the rows or more - the buffers are then at most about four times what they need to be, and the pass
+    // saves a kernel, a second reading of row ids and offsets, and the wait between the two.
+    bool fuse = utf8_gather_fused_available() && m > 0;
+    if (fuse && !pending)
+      for (size_t j = g0; j < g1; ++j) fuse = fuse && m * 4 >= srcs[j]->length;
     for (size_t j = g0; j < g1; ++j) {
       const Column &src = *srcs[j];
       Column &c = out[j];
@@ -217,7 +224,7 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
         g.control = (char *)scratch->ptr + (j - g0) * CONTROL_BYTES;
         g.status = (char *)scratch->ptr + (cols * CONTROL_BYTES + 63) / 64 * 64 + (j - g0) * status_bytes;
       }
-      if (pending) {
+      if (pending || fuse) {
         // no selection keeps more bytes than the column has
         c.values_bytes = std::max<int64_t>(src.values_bytes, 0);
         c.values = device_buffer(ctx, (size_t)c.values_bytes + 16);
@@ -225,13 +232,24 @@ static std::vector<Column> utf8_gather_columns(Context *ctx, const std::vector<c
       }
     }
     if (m <= 0) continue;
-    if (pending && utf8_gather_fused_available()) {
+    if (fuse) {
       // the output bytes' buffers exist already: offsets and bytes in one pass (the tile that places its rows copies them)
       ctx->prof_begin("qe_utf8_gather_fused_kernel");
       QE_HIP(launch_utf8_gather_fused(launch, idx, m, m_dev, ctx->dev.cus, ctx->stream));
       ctx->prof_end();
-      // (with an arena the caller copies every column's words, and the filter's, in one go)
-      if (!arena) QE_HIP(hipMemcpyAsync(pending->host + CONTROL_WORDS * (first_slot + g0), scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+      if (pending) {
+        // (with an arena the caller copies every column's words, and the filter's, in one go)
+        if (!arena) QE_HIP(hipMemcpyAsync(pending->host + CONTROL_WORDS * (first_slot + g0), scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+        continue;
+      }
+      QE_HIP(hipMemcpyAsync(ctx->host_counters + FIRST_WORD, scratch->ptr, cols * CONTROL_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+      ctx->sync();
+      for (size_t j = g0; j < g1; ++j) {
+        const unsigned long long *w = ctx->host_counters + FIRST_WORD + CONTROL_WORDS * (j - g0);
+        if (w[2] != 0) fail(QE_ERR_INTERNAL, "string gather look-back timed out");
+        if (w[1] > 2147483647ull) fail(QE_ERR_INVALID_ARGUMENT, "the selected strings of one column exceed 2^31 - 1 bytes: scan smaller batches");
+        out[j].values_bytes = (int64_t)w[1];
+      }
       continue;
     }
     // lengths by row id, scanned into offsets, in one pass over all columns of the group; offs[m] = a column's byte total
