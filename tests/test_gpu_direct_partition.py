@@ -222,3 +222,34 @@ def test_more_groups_than_the_partitions_tables_hold(qe, torch_ctx, n_keys, skew
     last = torch.ones_like(first)
     last[:-1] = first[1:]
     assert np.array_equal(got[4], vv[first].cpu().numpy()) and np.array_equal(got[5], vv[last].cpu().numpy())
+
+
+def test_several_value_columns_and_partitions_folded_in_passes(qe, torch_ctx):
+    """Five accumulators over two value columns and a million groups: the log carries two value columns (no pairs, so
+    neither the one-pass scatter nor the direct first pass), a partition's table holds fewer groups than it gets, and
+    each partition is folded in two passes.  Sums against torch, minima and maxima bit for bit."""
+    torch, ctx = torch_ctx
+    n = 24_000_001
+    k, a, b, _ = columns(torch, ctx, n, seed=11)
+    C = qe.ColumnExpression
+    aggs = [qe.SumExpression(C(1)), qe.SumExpression(C(2)), qe.MinExpression(C(1)), qe.MaxExpression(C(2)), qe.AvgExpression(C(2)), qe.CountExpression(None)]
+    half = n // 2 - 5
+    batches = [qe.Batch.from_torch(ctx, [t[s:e] for t in (k, a, b)]) for s, e in ((0, half), (half, n))]
+    ctx.profile(True)
+    got = by_key(list(qe.AggregateExec([qe.ScanExec(ctx, batches)], [C(0)], aggs, group_capacity_hint=1_100_000).execute())[0].columns())
+    names = kernels_of(ctx)
+    ctx.profile(False)
+    assert any(name.startswith("qe_aggregate_partitioned") for name in names), names
+    dev = k.device
+    uk, inv, cnt = torch.unique(k, return_inverse=True, return_counts=True)
+    g = uk.shape[0]
+    assert np.array_equal(got[0], uk.cpu().numpy()) and np.array_equal(got[6], cnt.cpu().numpy())
+    for col, t in ((1, a), (2, b)):
+        ref = torch.zeros(g, dtype=torch.float64, device=dev).scatter_add_(0, inv, t).cpu().numpy()
+        mag = torch.zeros(g, dtype=torch.float64, device=dev).scatter_add_(0, inv, t.abs()).cpu().numpy()
+        assert (np.abs(got[col] - ref) <= 2 * REL * mag).all()
+        if col == 2:
+            assert (np.abs(got[5] - ref / got[6]) <= 2 * REL * mag / got[6]).all()
+    ref_min = torch.full((g,), 9.0, dtype=torch.float64, device=dev).scatter_reduce_(0, inv, a, "amin").cpu().numpy()
+    ref_max = torch.full((g,), -9.0, dtype=torch.float64, device=dev).scatter_reduce_(0, inv, b, "amax").cpu().numpy()
+    assert np.array_equal(got[3], ref_min) and np.array_equal(got[4], ref_max)
