@@ -1041,7 +1041,7 @@ static size_t read_ahead_copy_slices() {
 
 // Starts reading chunk (row_group, column) into the next staging buffer, a job of the pool per slice - for chunks that
 // are stored uncompressed (the file's bytes are the image the device decodes); others are read when their turn comes.
-static void read_ahead_issue(Context *ctx, ParquetFile &file, ParquetReadAhead &ahead, int row_group, int column) {
+static void read_ahead_issue(Context *ctx, ParquetFile &file, ParquetReadAhead &ahead, int row_group, int column, bool scans_last = false) {
   ParquetReadAhead::Read r;
   r.row_group = row_group;
   r.column = column;
@@ -1074,7 +1074,8 @@ static void read_ahead_issue(Context *ctx, ParquetFile &file, ParquetReadAhead &
     if (n_slices == 0) QE_HIP(hipEventRecord(images, copy_stream));
     // slices are what a reader reads at a time, groups of them what travels in one copy (a copy has a fixed cost on
     // the device's side: 4 MiB copies reached 44 GB/s where 8 MiB ones reached 47-49)
-    const size_t per_group = read_ahead_copy_slices();
+    // (the scan's last chunk: a copy per slice - nothing else is left to keep the link busy while a group fills)
+    const size_t per_group = scans_last ? 1 : read_ahead_copy_slices();
     r.progress->group_landed.assign((n_slices + per_group - 1) / per_group, 0);
     for (size_t i = 0; i < n_slices; ++i)
       IoPool::get().submit([pr = r.progress, f, start, dst, dev, len, slice, i, trace, device, copy_stream, images, per_group, n_slices] {
@@ -1160,7 +1161,7 @@ Batch parquet_read_row_group(Context *ctx, ParquetFile &file, int row_group, con
       size_t in_flight = 0;
       for (const ParquetReadAhead::Read &r : ahead->queue) in_flight += r.bytes;
       while ((int)ahead->queue.size() < READ_AHEAD_DEPTH && (ahead->queue.size() < 2 || in_flight < READ_AHEAD_BYTES) && at < columns.size() && next_of(g, at)) {
-        read_ahead_issue(ctx, file, *ahead, g, columns[at]);
+        read_ahead_issue(ctx, file, *ahead, g, columns[at], g == last_row_group - 1 && at + 1 == columns.size());
         in_flight += ahead->queue.back().bytes;
       }
       mine = std::move(ahead->queue.front());
