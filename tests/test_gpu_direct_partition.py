@@ -224,10 +224,10 @@ def test_more_groups_than_the_partitions_tables_hold(qe, torch_ctx, n_keys, skew
     assert np.array_equal(got[4], vv[first].cpu().numpy()) and np.array_equal(got[5], vv[last].cpu().numpy())
 
 
-def test_several_value_columns_and_partitions_folded_in_passes(qe, torch_ctx):
+def test_several_value_columns_and_more_partitions_than_512(qe, torch_ctx):
     """Five accumulators over two value columns and a million groups: the log carries two value columns (no pairs, so
-    neither the one-pass scatter nor the direct first pass), a partition's table holds fewer groups than it gets, and
-    each partition is folded in two passes.  Sums against torch, minima and maxima bit for bit."""
+    neither the one-pass scatter nor the direct first pass, and no folding of a partition in passes either): 1024
+    partitions through the two scatter levels.  Sums against torch, minima and maxima bit for bit."""
     torch, ctx = torch_ctx
     n = 24_000_001
     k, a, b, _ = columns(torch, ctx, n, seed=11)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small single-GPU driver for profiling one configuration under rocprofv3.
 
-usage: probe.py <c2|c3|c5|c4|c5m|c5mp|p|utf8> [rows] [reps] [batches]   (the rows in that many equal batches, default 1; c5m: the c5 plan over 1 M uniform keys; utf8: the reference's
+usage: probe.py <c2|c3|c5|c4|c4b|c5m|c5mp|p|utf8> [rows] [reps] [batches]   (the rows in that many equal batches, default 1; c5m: the c5 plan over 1 M uniform keys; utf8: the reference's
 test_filter shape at 100 M rows, bench.py's utf8_filter_config, with the deferred row count)
 """
 import importlib
@@ -35,7 +35,7 @@ def main():
     a = torch.empty(n, dtype=torch.float64, device=dev)
     b = torch.empty(n, dtype=torch.float64, device=dev)
     c = torch.empty(n, dtype=torch.float64, device=dev)
-    if cfg == "c4":
+    if cfg in ("c4", "c4b"):
         ctx.generate(2, 77, 0, n, 1_000_000, 1.1, k.data_ptr())
     elif cfg in ("c5m", "c5mp"):
         ctx.generate(1, 99, 0, n, 0, int(os.environ.get("QE_PROBE_KEYS", "1000000")), k.data_ptr())
@@ -59,6 +59,9 @@ def main():
         if cfg == "c4":
             return qe.AggregateExec([scan], [C(0)], [qe.SumExpression(C(3)), qe.MinExpression(C(3)), qe.MaxExpression(C(3)),
                                                       qe.AvgExpression(C(3))], group_capacity_hint=1_100_000)
+        if cfg == "c4b":  # the same keys, accumulators over two value columns: the log carries two value columns, not (key, value) pairs
+            return qe.AggregateExec([scan], [C(0)], [qe.SumExpression(C(3)), qe.SumExpression(C(2)), qe.MinExpression(C(3)), qe.MaxExpression(C(2))],
+                                    group_capacity_hint=int(os.environ.get("QE_PROBE_HINT", "1100000")))
         if cfg == "p":
             return qe.ProjectionExec([scan], [qe.AddExpression(C(1), qe.MulExpression(C(2), C(3)))])
         sel = qe.SelectionExec([scan], qe.GtExpression(C(3), qe.LiteralFloatExpression(0.5)))
