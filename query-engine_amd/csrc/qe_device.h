@@ -1518,7 +1518,24 @@ struct SpillState {
   uint64_t base;     // first row of this wave's region
   uint32_t cursor;   // rows logged so far (wave-uniform)
   uint32_t pairs;    // AggSpill::pairs
+  uint32_t null_cols, null_f64;  // AggSpill::null_cols / null_f64
 };
+
+// What the log holds for value `v` of value column `col` (AggSpill::null_cols).
+__device__ __forceinline__ unsigned long long spill_logged_value(uint32_t null_cols, uint32_t null_f64, uint32_t col, unsigned long long v, bool valid) {
+  if (!((null_cols >> col) & 1u)) return v;  // (uniform)
+  if ((null_f64 >> col) & 1u) return valid ? (v == SPILL_NULL_F64 ? SPILL_PLAIN_NAN : v) : SPILL_NULL_F64;
+  return valid ? v : SPILL_NULL_INT;
+}
+// Rows (bits of `rows`) whose logged value of column `col` is not the null mark.
+__device__ __forceinline__ uint32_t spill_valid_rows(uint32_t null_cols, uint32_t null_f64, uint32_t col, const uint64_t (&v)[VM_R], uint32_t rows) {
+  if (!((null_cols >> col) & 1u)) return rows;  // (uniform)
+  const uint64_t mark = ((null_f64 >> col) & 1u) ? (uint64_t)SPILL_NULL_F64 : (uint64_t)SPILL_NULL_INT;
+#pragma unroll
+  for (int j = 0; j < VM_R; ++j)
+    if (v[j] == mark) rows &= ~(1u << j);
+  return rows;
+}
 
 __device__ __forceinline__ SpillState spill_begin(const AggSpill &sp, uint32_t wave_in_block) {
   SpillState s;
@@ -1528,6 +1545,8 @@ __device__ __forceinline__ SpillState spill_begin(const AggSpill &sp, uint32_t w
   s.base = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block) * sp.rows_per_wave;
   s.cursor = 0;
   s.pairs = sp.pairs;
+  s.null_cols = sp.null_cols;
+  s.null_f64 = sp.null_f64;
   return s;
 }
 __device__ __forceinline__ void spill_end(const AggSpill &sp, const SpillState &s, uint32_t wave_in_block, uint32_t lane) {
@@ -1541,7 +1560,7 @@ __device__ __forceinline__ void spill_values(const SpillState &sp, uint32_t col,
   uint32_t k = 0;
 #pragma unroll
   for (int j = 0; j < VM_R; ++j) {
-    if ((G.spill_mb >> j) & 1u) dst[k << sp.pairs] = in.v[j];
+    if ((G.spill_mb >> j) & 1u) dst[k << sp.pairs] = spill_logged_value(sp.null_cols, sp.null_f64, col, in.v[j], ((in.valid >> j) & 1u) != 0);
     k += (G.spill_mb >> j) & 1u;
   }
 }

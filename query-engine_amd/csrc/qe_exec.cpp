@@ -818,7 +818,10 @@ static int add_fix_sum(AggSpec &spec, const ExprPtr &x, int S, bool track_nn, ui
 static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::vector<ExprPtr> &groups,
                               const std::vector<AggExpr> &aggs, const std::vector<ExprPtr> &aggs_second, int mode,
                               int64_t row_base = 0, bool emit_row_number = false, const std::vector<int> *fix_scales = nullptr,
-                              uint64_t fix_overflow_word = 0) {
+                              uint64_t fix_overflow_word = 0, bool explicit_counts = false) {
+  // `explicit_counts`: whether a SUM (or an integer MIN / MAX) over a nullable input has seen a value at all is told by
+  // a COUNT accumulator over the same input, not by the validity counters beside the accumulators - the many-groups
+  // mode's log and partition passes carry accumulators only.
   AggSpec spec;
   int shift = 0;
   if ((int)groups.size() > MAX_HASHED_KEYS) fail(QE_ERR_PHYSICAL_EXPRESSION_NOT_SUPPORTED, "Too many group expressions.");
@@ -912,6 +915,11 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
         need_numeric();
         bool is_min = ag.kind == QE_AGG_MIN;
         bool f64 = t == QE_TYPE_FLOAT64;
+        if (explicit_counts && nullable && !f64) {
+          const int a = add_acc(spec, is_min ? ACC_MIN : ACC_MAX, t, false, e), b = add_acc(spec, ACC_COUNT, t, false, e);
+          spec.outs.push_back(fin(FIN_ACC_ORD, t, a, b, CNT_ACC, NULL_IF_COUNT_ZERO));
+          break;
+        }
         int a = add_acc(spec, is_min ? ACC_MIN : ACC_MAX, t, nullable && !f64, e);
         uint8_t nm = f64 ? (is_min ? NULL_IF_ACC_ALL_ONES : NULL_IF_ACC_ZERO) : (nullable ? NULL_IF_COUNT_ZERO : NULL_NEVER);
         spec.outs.push_back(fin(FIN_ACC_ORD, t, a, a, CNT_NN, nm));
@@ -925,6 +933,11 @@ static AggSpec build_agg_spec(uint32_t flags, const Schema &schema, const std::v
           FinOut f = fin(FIN_FIX_SUM, t, a, a, CNT_NN, nullable ? NULL_IF_COUNT_ZERO : NULL_NEVER);
           f.scale = (int16_t)(*fix_scales)[i];
           spec.outs.push_back(f);
+          break;
+        }
+        if (explicit_counts && nullable) {
+          const int a = add_acc(spec, f64 ? ACC_SUM_F64 : ACC_SUM_I64, t, false, e), b = add_acc(spec, ACC_COUNT, t, false, e);
+          spec.outs.push_back(fin(f64 ? FIN_ACC_F64 : FIN_ACC_I64, t, a, b, CNT_ACC, NULL_IF_COUNT_ZERO));
           break;
         }
         int a = add_acc(spec, f64 ? ACC_SUM_F64 : ACC_SUM_I64, t, nullable, e);
@@ -1118,12 +1131,17 @@ static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &b
   const bool wanted = group_hint >= spill_min_group_hint() ||
                       (midrange && !deferred && args.n_rows >= (1 << 20) && (group_hint == 0 || group_hint >= 512));
   if (!spill_enabled() || !wanted || args.n_rows >= (1ll << 31) || args.n_accs == 0) return sp;
-  // the log carries values only: every accumulator must read a non-nullable input
+  // the log carries values only: an accumulator reads a non-nullable input, or one whose nulls can be marked
   std::vector<std::string> inputs;
+  uint16_t null_cols = 0, null_f64 = 0;
   for (int i = 0; i < args.n_accs; ++i) {
     const AccDesc &d = bspec.accs[i];
-    // (a float64 MIN / MAX has no validity tracking of its own - a null is skipped like a NaN - but its input can be null all the same)
-    if (!d.input || args.accs[i].track_nn || args.accs[i].op == ACC_COUNT || expr_nullable(d.input, schema)) return sp;
+    if (!d.input || args.accs[i].track_nn) return sp;
+    // An input that can be null (a float64 MIN / MAX has no validity tracking of its own - a null is skipped like a
+    // NaN - but its input can be null all the same; a COUNT counts the valid ones) is logged with a mark for nulls:
+    // Float64 and Int32 inputs have bit patterns to spare for one, Int64 inputs have not.
+    const bool marks_nulls = args.accs[i].op == ACC_COUNT || expr_nullable(d.input, schema);
+    if (marks_nulls && args.accs[i].in_type != VT_F64 && args.accs[i].in_type != VT_I32) return sp;
     std::string key = expr_identity(d.input);
     size_t col = 0;
     while (col < inputs.size() && inputs[col] != key) ++col;
@@ -1133,6 +1151,10 @@ static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &b
       args.spill_col[i] = (uint8_t)col;  // the first accumulator with this input logs it
     }
     sp.acc_col[i] = (uint8_t)col;
+    if (marks_nulls) {
+      null_cols |= (uint16_t)(1u << col);
+      if (args.accs[i].in_type == VT_F64) null_f64 |= (uint16_t)(1u << col);
+    }
   }
   // Rows will miss the workgroups' tables in numbers: when a kernel specialised for the shape exists, one wide workgroup
   // per compute unit with a table of four times the slots (fewer rows in the log, the same waves in flight)
@@ -1158,6 +1180,8 @@ static SpillPlan plan_spill(Context *ctx, const Schema &schema, const AggSpec &b
   a.rows_per_wave = (uint32_t)((steps_per_wave + (args.n_more > 0 ? args.n_more + 2 : 0)) * VM_WAVE_ROWS + region_pad);
   a.capacity = (uint64_t)sp.waves * a.rows_per_wave;
   a.n_inputs = (uint32_t)inputs.size();
+  a.null_cols = null_cols;
+  a.null_f64 = null_f64;
   static const bool pairs_on = [] {
     const char *e = getenv("QE_SPILL_PAIRS");  // 0: a key column and a value column whatever the number of value columns
     return e ? atoi(e) != 0 : true;
@@ -1315,6 +1339,8 @@ static void aggregate_spilled(Context *ctx, const SpillPlan &sp, const AggArgs &
   pa.lds_limit = pa.lds_cap - pa.lds_cap / 4;
   pa.part_bits = bits;
   pa.sub_bits = sp.sub_bits;
+  pa.null_cols = args.spill.null_cols;
+  pa.null_f64 = args.spill.null_f64;
   pa.ticket = total + 1;
   ctx->prof_begin("qe_aggregate_partitioned_kernel");
   QE_HIP(launch_aggregate_partitioned(pa, ctx->dev, ctx->stream));
@@ -1426,7 +1452,7 @@ struct AggState {
 
   void spill_attach(SpillPlan &sp, AggArgs &args) {
     SpillGroup &g = spill_group;
-    if (!g.items.empty() && (g.bits != sp.bits || g.sub_bits != sp.sub_bits || g.blocks != sp.blocks || g.n_accs != args.n_accs || (int)g.items.size() >= g.slots ||
+    if (!g.items.empty() && (g.bits != sp.bits || g.sub_bits != sp.sub_bits || g.blocks != sp.blocks || g.items[0].spill.null_cols != args.spill.null_cols || g.n_accs != args.n_accs || (int)g.items.size() >= g.slots ||
                              g.log_rows + args.spill.capacity >= (1ull << 31)))
       spill_flush();
     if (g.items.empty()) {
@@ -1534,6 +1560,8 @@ struct AggState {
       pa.lds_limit = pa.lds_cap - pa.lds_cap / 4;
       pa.part_bits = g.bits;
       pa.sub_bits = g.sub_bits;
+      pa.null_cols = g.items[0].spill.null_cols;
+      pa.null_f64 = g.items[0].spill.null_f64;
       pa.ticket = total + 1;
       pa.direct_blocks = g.blocks;
       for (auto &it : g.items)
@@ -1813,8 +1841,13 @@ struct AggState {
       if (fitter.temporaries) schema = fitter.schema;
       had_temporaries = fitter.temporaries != 0;
     }
+    static const bool spill_nullable = [] {
+      const char *e = getenv("QE_SPILL_NULLABLE");  // 0: nullable accumulator inputs keep an aggregation out of the many-groups mode
+      return e ? atoi(e) != 0 : true;
+    }();
     AggSpec bspec = build_agg_spec(ctx->flags, schema, g2, a2, a2_second, mode, row_base, emit_row_number, any_fix ? &scales_now : nullptr,
-                                   any_fix && fix_overflow ? (uint64_t)(uintptr_t)fix_overflow->ptr : 0);
+                                   any_fix && fix_overflow ? (uint64_t)(uintptr_t)fix_overflow->ptr : 0,
+                                   spill_nullable && spill_enabled() && effective_hint() >= spill_min_group_hint());
     key_sources.resize(bspec.key_gathers.size());
     for (size_t i = 0; i < bspec.key_gathers.size(); ++i) key_sources[i].push_back(Utf8KeySource{in.cols[bspec.key_gathers[i].col], row_base});
     if (!bspec.key_gathers.empty() && !(ctx->flags & QE_FLAG_HASH_ONLY_GROUP_IDENTITY))

@@ -822,6 +822,7 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
 #pragma unroll
               for (int j = 0; j < VM_R; ++j) in.v[j] = ((active >> j) & 1u) ? A.vals[(uint64_t)v * A.capacity + r0 + j * 64 + lane] : 0ull;
             }
+            const uint32_t use = spill_valid_rows(A.null_cols, A.null_f64, (uint32_t)v, in.v, active);  // (a logged null is a row, not a value)
 #pragma unroll 1
             for (int a = 0; a < A.n_accs; ++a) {
               if (A.acc_col[a] != v) continue;
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
 #pragma unroll
                 for (int j = 0; j < VM_R; ++j) {
                   const bool nan = in_type == VT_F64 && u2d(in.v[j]) != u2d(in.v[j]);  // NaN is ignored by min / max
-                  if (!nan && ((active >> j) & 1u)) {
+                  if (!nan && ((use >> j) & 1u)) {
                     if (op == ACC_MIN) atomicMin(acc + slot[j], (unsigned long long)ord_image(in.v[j], in_type));
                     else atomicMax(acc + slot[j], (unsigned long long)ord_image(in.v[j], in_type));
                   }
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
               } else {
 #pragma unroll
                 for (int j = 0; j < VM_R; ++j)
-                  if ((active >> j) & 1u) acc_apply(acc + slot[j], op, op == ACC_COUNT ? 1ull : in.v[j]);
+                  if ((use >> j) & 1u) acc_apply(acc + slot[j], op, op == ACC_COUNT ? 1ull : in.v[j]);
               }
             }
           }
@@ -863,6 +864,7 @@ __global__ __launch_bounds__(PART_THREADS) void qe_aggregate_partitioned_kernel(
 #pragma unroll
           for (int j = 0; j < VM_R; ++j) in.v[j] = ((active >> j) & 1u) ? A.vals[(uint64_t)v * A.capacity + r0 + j * 64 + lane] : 0ull;
         }
+        in.valid = spill_valid_rows(A.null_cols, A.null_f64, (uint32_t)v, in.v, 0xFu);
 #pragma unroll 1
         for (int a = 0; a < A.n_accs; ++a)
           if (A.acc_col[a] == v) agg_fold(L, A.table, a, A.accs[a].op, A.accs[a].in_type, false, in, G, lane);

@@ -891,12 +891,13 @@ __device__ __forceinline__ void spill_tasks_static(const AggArgs &A, const LdsTa
           ulonglong2 *dst = (ulonglong2 *)sp.keys + G.pos;
 #pragma unroll
           for (int j = 0; j < VM_R; ++j)
-            if ((G.miss >> j) & 1u) dst[G.off[j]] = make_ulonglong2((unsigned long long)G.key[j], (unsigned long long)S[0].v[j]);
+            if ((G.miss >> j) & 1u)
+              dst[G.off[j]] = make_ulonglong2((unsigned long long)G.key[j], spill_logged_value(sp.null_cols, sp.null_f64, 0, S[0].v[j], ((S[0].valid >> j) & 1u) != 0));
         } else {
           unsigned long long *dst = sp.vals + (uint64_t)A.spill_col[idx] * sp.capacity + G.pos;
 #pragma unroll
           for (int j = 0; j < VM_R; ++j)
-            if ((G.miss >> j) & 1u) dst[G.off[j]] = S[0].v[j];
+            if ((G.miss >> j) & 1u) dst[G.off[j]] = spill_logged_value(sp.null_cols, sp.null_f64, A.spill_col[idx], S[0].v[j], ((S[0].valid >> j) & 1u) != 0);
         }
       }
       if constexpr (Spec::n_accs <= SPILL_ROW_MAJOR_ACCS) {
@@ -1019,7 +1020,7 @@ __device__ __forceinline__ void direct_tasks_static(const AggArgs &A, RowCtx &c,
         for (int j = 0; j < VM_R; ++j) S[0].v[j] = 1;
         if constexpr (Spec::task_eval[T] != 0) eval_static<Spec, Spec::task_pc[T]>(A.prog, c, K, S);
 #pragma unroll
-        for (int j = 0; j < VM_R; ++j) val[j] = S[0].v[j];
+        for (int j = 0; j < VM_R; ++j) val[j] = spill_logged_value(A.spill.null_cols, A.spill.null_f64, A.spill_col[idx], S[0].v[j], ((S[0].valid >> j) & 1u) != 0);
       }
     } else {
       Slot S[VM_MAX_DEPTH];

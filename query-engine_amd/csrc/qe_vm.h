@@ -231,8 +231,15 @@ struct AggSpill {
   // counts[0] is set when some stretch was too small for its rows (which are then missing: the caller runs the batch
   // again, through the log).
   uint32_t direct_cap;
-  uint32_t direct_pad;
+  // Value columns of the log whose input can be null (bit c: column c): a null is logged as a value no input holds -
+  // SPILL_NULL_F64 for a Float64 column (bit c of null_f64 set; an input NaN with that very payload is logged as the
+  // plain quiet NaN), SPILL_NULL_INT for an Int32 one (kept sign-extended in 64 bits, so INT64_MIN is free) - and the
+  // partition-wise aggregate leaves such a row out of the accumulators that read the column (it still counts as a row
+  // of its group).
+  uint16_t null_cols;
+  uint16_t null_f64;
 };
+constexpr unsigned long long SPILL_NULL_F64 = 0x7FF8000000006E75ull, SPILL_NULL_INT = 0x8000000000000000ull, SPILL_PLAIN_NAN = 0x7FF8000000000000ull;
 
 constexpr int AGG_MORE_BATCHES = 3;  // batches a first pass of the many-groups mode takes on top of its first
 
@@ -327,6 +334,7 @@ struct PartArgs {
   // More groups than n_parts tables hold: a partition is folded in 1 << sub_bits passes over its rows, each keeping
   // the rows whose next sub_bits hash bits (below the part_bits that name the partition) are the pass's number.
   int32_t part_bits, sub_bits;
+  uint16_t null_cols, null_f64;  // AggSpill::null_cols / null_f64 of the log the rows come from
 };
 
 constexpr int FIX_FRACTION_BITS = 96;  // fixed-point digits below 2^S
