@@ -161,3 +161,31 @@ def test_nullable_input_at_size_against_torch(qe):
         torch.cuda.synchronize()
         ctx.close()
         torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def test_partial_aggregates_of_nullable_inputs_merged_by_a_final_one(qe, jit):
+    """PARTIAL aggregates of two parts (their partial sums are null for groups that saw no value) merged by a FINAL one,
+    all three in the many-groups mode: the same groups, counts, minima and maxima as the single aggregate over both
+    parts, sums within 1e-12 of the magnitudes."""
+    from test_gpu_parity import mk
+    from util import gpu_batch
+    parts_in = [columns(500_000, seed=301), columns(450_000, seed=302)]
+    aggs = lambda: [mk(qe, a) for a in [("sum", C(1)), ("count", C(1)), ("count", None), ("min", C(1)), ("max", C(1)), ("avg", C(1))]]
+    whole = list(qe.AggregateExec([qe.ScanExec(jit, [gpu_batch(qe, jit, p) for p in parts_in])], [mk(qe, C(0))], aggs(), group_capacity_hint=HINT).execute())[0].columns()
+    partials = []
+    for p in parts_in:
+        partials += list(qe.AggregateExec([qe.ScanExec(jit, [gpu_batch(qe, jit, p)])], [mk(qe, C(0))], aggs(), mode=qe.AGG_MODE_PARTIAL, group_capacity_hint=HINT).execute())
+    merged = list(qe.final_plan(qe.ScanExec(jit, partials), 1, aggs(), group_capacity_hint=HINT).execute())[0].columns()
+    assert len(merged) == len(whole)
+    ow, om = np.argsort(np.asarray(whole[0].values)), np.argsort(np.asarray(merged[0].values))
+    for i, (w, m) in enumerate(zip(whole, merged)):
+        wv, mv = np.asarray(w.values)[ow], np.asarray(m.values)[om]
+        wval = np.ones(len(wv), bool) if w.validity is None else np.asarray(w.validity, dtype=bool)[ow]
+        mval = np.ones(len(mv), bool) if m.validity is None else np.asarray(m.validity, dtype=bool)[om]
+        assert np.array_equal(wval, mval), i
+        if i in (1, 6):  # sum, avg
+            assert (np.abs(wv[wval] - mv[wval]) <= 1e-12 * 100 * 50).all(), i
+        else:
+            assert np.array_equal(wv[wval], mv[wval]), i
+    null_keys = np.asarray(whole[0].values)[ow] < 2000  # (the keys whose every value is null)
+    assert null_keys.any() and not np.asarray(whole[1].validity, dtype=bool)[ow][null_keys].any()
