@@ -581,12 +581,13 @@ SAMPLER, SAMPLER_PCI, LAST_WINDOW = None, None, None
 
 
 def timed(ctx, torch, fn, steps, warmup):
+    """Seconds per step over `steps` steps with nothing timed inside them, then the same steps once more with HIP events
+    around every launch for the kernels' own times: a pair of events per launch is not free (a step of a dozen launches
+    paid a tenth of a millisecond for them), and the step is what the end-to-end figures are made of."""
     global LAST_WINDOW
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
-    ctx.profile(True)
-    ctx.profile_read()
     w0 = time.time()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -594,6 +595,11 @@ def timed(ctx, torch, fn, steps, warmup):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     LAST_WINDOW = (w0, time.time())
+    ctx.profile(True)
+    ctx.profile_read()
+    for _ in range(steps):
+        r = fn()
+    torch.cuda.synchronize()
     prof = ctx.profile_read()
     ctx.profile(False)
     return dt, prof, r
