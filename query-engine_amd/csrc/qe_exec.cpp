@@ -1430,7 +1430,10 @@ struct AggState {
 
   int acc_weight(const AggExpr &a) const {  // accumulators an aggregate may take
     const bool fix = fix_wanted();
-    return a.kind == QE_AGG_AVG ? (fix ? FIX_ACCS + 1 : 2) : (fix && a.kind == QE_AGG_SUM ? FIX_ACCS : 1);
+    // (with very many groups a SUM, MIN or MAX over an input that turns out nullable brings a COUNT accumulator along:
+    // build_agg_spec's explicit_counts)
+    const int plain = effective_hint() >= spill_min_group_hint() && a.kind != QE_AGG_COUNT ? 2 : 1;
+    return a.kind == QE_AGG_AVG ? (fix ? FIX_ACCS + 1 : 2) : (fix && a.kind == QE_AGG_SUM ? FIX_ACCS : plain);
   }
   static constexpr int PART_ACC_BUDGET = VM_MAX_ACCS - 2;                           // the row number, and one to spare
 

@@ -189,3 +189,13 @@ def test_partial_aggregates_of_nullable_inputs_merged_by_a_final_one(qe, jit):
             assert np.array_equal(wv[wval], mv[wval]), i
     null_keys = np.asarray(whole[0].values)[ow] < 2000  # (the keys whose every value is null)
     assert null_keys.any() and not np.asarray(whole[1].validity, dtype=bool)[ow][null_keys].any()
+
+
+def test_ten_sums_over_ten_nullable_columns(qe, jit):
+    """Each SUM brings a COUNT accumulator along in this mode: twenty accumulators are more than one kernel takes, so the
+    aggregate list is split and the parts' outputs joined - the same columns as the oracle's."""
+    r = rng(9)
+    n = 150_000
+    k = r.integers(0, 70_000, n).astype(np.int64)
+    cols = [orc.Array(orc.INT64, k)] + [orc.Array(orc.FLOAT64, r.uniform(-1, 1, n), r.random(n) > 0.1 * (i + 1) / 2) for i in range(10)]
+    run_agg(qe, jit, [cols], [C(0)], [("sum", C(1 + i)) for i in range(10)] + [("count", None)], hint=HINT, what="ten sums over ten nullable columns")
